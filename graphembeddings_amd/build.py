@@ -1,0 +1,50 @@
+"""Builds libge_hip.so (the C-ABI HIP library, include/ge_hip.h) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the built .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libge_hip.so")
+SOURCES = ["ge_capi.hip", "ge_complex.hip", "ge_rows.hip", "ge_hole.hip", "ge_1vk.hip"]
+HEADERS = ["ge_common.h", os.path.join("..", "..", "include", "ge_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libge_hip.so cannot be built (ROCm toolchain required)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    """Compile every HIP source into graphembeddings_amd/libge_hip.so. Returns the path."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-shared", "-fPIC",
+           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB + ".tmp"] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

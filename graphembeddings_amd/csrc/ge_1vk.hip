@@ -1,0 +1,215 @@
+// ge_1vk.hip -- 1-vs-K candidate scoring as an fp32-MFMA GEMM.
+//
+// Replaces the inference loop of holE.py:564-569 (itertools.product([head], tail_candidates,
+// relations) -> evaluate_triples per candidate) and serves K shared negatives per positive
+// (BASELINE config 5).  With q = clip(h) o clip(r) (complex product),
+//     score(h, r, t_j) = sum_k Re(q_k conj(t_jk)) = [Re q | Im q] . [Re t_j | Im t_j],
+// so S[B,K] = Q[B,d] . T[K,d]^T.  Every clip is a per-row scalar: the GEMM runs on the RAW rows
+// (Q_raw = fixed o rel formed on the fly while staging) and the product of the three clip scales is
+// applied in the epilogue, fused with the sigmoid (holE.py:198).
+//
+// MFMA: v_mfma_f32_32x32x2_f32 -- exact fp32 (a k-ordered fmaf chain), which keeps the result
+// within 1e-5 of the fp32 reference arithmetic; bf16 MFMA would not.  Block = 4 waves as 2x2, each
+// wave TM x TN tiles of 32x32; k is walked in chunks of 16 complex dims (= 32 real k) staged in LDS
+// with a row stride of 33 floats so the 32 rows a half-wave reads per operand fall in 32 banks.
+#include "ge_common.h"
+
+namespace ge {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int KC = 16;   // complex dims per chunk
+constexpr int LDA = 33;  // LDS row stride (floats): 2*KC + 1
+
+template <bool V4>
+__device__ __forceinline__ void load4(const float* __restrict__ row, int c0, int k, bool im, float (&v)[4]) {
+  // 4 consecutive complex-dim values c0..c0+3 of the real (im=false) or imaginary half
+  const float* p = row + (im ? k : 0) + c0;
+  if (V4) {
+    if (c0 + 3 < k) {
+      const float4 x = *reinterpret_cast<const float4*>(p);
+      v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+      return;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = (c0 + q < k) ? p[q] : 0.f;
+}
+
+template <int TM, int TN, bool V4>
+__global__ __launch_bounds__(kBlock) void score_1vK_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
+    const int32_t* __restrict__ cand, int64_t K, float max_norm, int apply_sigmoid, int cand_is_head,
+    float* __restrict__ out) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  __shared__ float As[BM * LDA];
+  __shared__ float Bs[BN * LDA];
+  __shared__ float sA[BM];
+  __shared__ float sB[BN];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int lrow = t >> 2, lj = t & 3;
+  const int k = d >> 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+  int32_t fid[TM], rid[TM], cid[TN];
+  bool abad[TM], bbad[TN];
+#pragma unroll
+  for (int p = 0; p < TM; ++p) {
+    const int64_t r = m0 + lrow + 64 * p;
+    fid[p] = -1; rid[p] = -1; abad[p] = false;
+    if (r < B) {
+      fid[p] = hr[2 * r]; rid[p] = hr[2 * r + 1];
+      abad[p] = fid[p] < 0 || fid[p] >= N || rid[p] < 0 || rid[p] >= N;
+      if (abad[p]) { fid[p] = -1; rid[p] = -1; }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < TN; ++p) {
+    const int64_t c = n0 + lrow + 64 * p;
+    cid[p] = -1; bbad[p] = false;
+    if (c < K) {
+      cid[p] = cand[c];
+      bbad[p] = cid[p] < 0 || cid[p] >= N;
+      if (bbad[p]) cid[p] = -1;
+    }
+  }
+  float ssf[TM], ssr[TM], ssc[TN];
+#pragma unroll
+  for (int p = 0; p < TM; ++p) { ssf[p] = 0.f; ssr[p] = 0.f; }
+#pragma unroll
+  for (int p = 0; p < TN; ++p) ssc[p] = 0.f;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  for (int kc = 0; kc < k; kc += KC) {
+    const int c0 = kc + 4 * lj;
+#pragma unroll
+    for (int p = 0; p < TM; ++p) {
+      float qre[4] = {0.f, 0.f, 0.f, 0.f}, qim[4] = {0.f, 0.f, 0.f, 0.f};
+      if (fid[p] >= 0 && c0 < k) {
+        float fre[4], fim[4], rre[4], rim[4];
+        const float* frow = table + (int64_t)fid[p] * d;
+        const float* rrow = table + (int64_t)rid[p] * d;
+        load4<V4>(frow, c0, k, false, fre); load4<V4>(frow, c0, k, true, fim);
+        load4<V4>(rrow, c0, k, false, rre); load4<V4>(rrow, c0, k, true, rim);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ssf[p] += fre[q] * fre[q] + fim[q] * fim[q];
+          ssr[p] += rre[q] * rre[q] + rim[q] * rim[q];
+          if (!cand_is_head) {  // q = h * r
+            qre[q] = fre[q] * rre[q] - fim[q] * rim[q];
+            qim[q] = fre[q] * rim[q] + fim[q] * rre[q];
+          } else {              // Re(h * r * conj(t)): Q = [Re(r conj t) | -Im(r conj t)]
+            qre[q] = rre[q] * fre[q] + rim[q] * fim[q];
+            qim[q] = -(rim[q] * fre[q] - rre[q] * fim[q]);
+          }
+        }
+      }
+      float* dst = As + (lrow + 64 * p) * LDA + 4 * lj;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dst[q] = qre[q]; dst[KC + q] = qim[q]; }
+    }
+#pragma unroll
+    for (int p = 0; p < TN; ++p) {
+      float cre[4] = {0.f, 0.f, 0.f, 0.f}, cim[4] = {0.f, 0.f, 0.f, 0.f};
+      if (cid[p] >= 0 && c0 < k) {
+        const float* crow = table + (int64_t)cid[p] * d;
+        load4<V4>(crow, c0, k, false, cre); load4<V4>(crow, c0, k, true, cim);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ssc[p] += cre[q] * cre[q] + cim[q] * cim[q];
+      }
+      float* dst = Bs + (lrow + 64 * p) * LDA + 4 * lj;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dst[q] = cre[q]; dst[KC + q] = cim[q]; }
+    }
+    __syncthreads();
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 2 * KC; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = As[(wm * 32 * TM + tm * 32 + li) * LDA + kk + lh];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(wn * 32 * TN + tn * 32 + li) * LDA + kk + lh];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // clip scales (get_embedding, holE.py:162) -> LDS
+  const float nanv = __builtin_nanf("");
+#pragma unroll
+  for (int p = 0; p < TM; ++p) {
+    float a = ssf[p], b = ssr[p];
+    a += __shfl_xor(a, 1, kWave); a += __shfl_xor(a, 2, kWave);
+    b += __shfl_xor(b, 1, kWave); b += __shfl_xor(b, 2, kWave);
+    if (lj == 0) {
+      float i0, i1;
+      sA[lrow + 64 * p] = abad[p] ? nanv : clip_scale(a, max_norm, i0) * clip_scale(b, max_norm, i1);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < TN; ++p) {
+    float c = ssc[p];
+    c += __shfl_xor(c, 1, kWave); c += __shfl_xor(c, 2, kWave);
+    if (lj == 0) {
+      float i0;
+      sB[lrow + 64 * p] = bbad[p] ? nanv : clip_scale(c, max_norm, i0);
+    }
+  }
+  __syncthreads();
+
+  // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int cl = wn * 32 * TN + tn * 32 + li;
+      const int64_t col = n0 + cl;
+      const float sb = sB[cl];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rl = wm * 32 * TM + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int64_t row = m0 + rl;
+        if (row < B && col < K) {
+          const float s = acc[tm][tn][q] * sA[rl] * sb;
+          out[row * K + col] = apply_sigmoid ? sigmoidf_dev(s) : s;
+        }
+      }
+    }
+}
+
+int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
+                             const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
+                             int cand_is_head, float* out, hipStream_t st) {
+  if (d <= 0 || (d & 1)) return GE_EINVAL;
+  if (B == 0 || K == 0) return 0;
+  const int k = d / 2;
+  const bool v4 = (k % 4 == 0) && (reinterpret_cast<uintptr_t>(table) % 16 == 0);
+  const int64_t big_blocks = ((B + 127) / 128) * ((K + 127) / 128);
+  const bool big = big_blocks >= 512;
+  const int bm = big ? 128 : 64;
+  const int64_t gy = (B + bm - 1) / bm, gx = (K + bm - 1) / bm;
+  if (gy > 65535 || gx > 2147483647LL) return GE_ENOTSUP;
+  dim3 grid((unsigned)gx, (unsigned)gy);
+#define L1VK(TM, TN, V) \
+  hipLaunchKernelGGL((score_1vK_kernel<TM, TN, V>), grid, dim3(kBlock), 0, st, table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out)
+  if (big) { if (v4) L1VK(2, 2, true); else L1VK(2, 2, false); }
+  else { if (v4) L1VK(1, 1, true); else L1VK(1, 1, false); }
+#undef L1VK
+  return launch_status();
+}
+
+}  // namespace ge

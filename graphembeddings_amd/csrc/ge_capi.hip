@@ -1,0 +1,194 @@
+// ge_capi.hip -- the extern "C" boundary declared in include/ge_hip.h.
+// Argument checks happen here, on the host, before any launch: a kernel that faults can take
+// the whole node down, so shapes, alignment and workspace sizes are validated up front.
+#include "ge_common.h"
+
+namespace ge {
+int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
+int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t);
+int complex_max_dim();
+int hole_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
+int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
+int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t);
+int hole_max_dim();
+int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t);
+int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float*, hipStream_t);
+int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
+int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
+}  // namespace ge
+
+using namespace ge;
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline bool ok_table(const void* t, int64_t N, int32_t d) { return t != nullptr && N > 0 && d > 0; }
+static inline bool max_norm_ok(float m) { return m > 0.f; }
+
+extern "C" {
+
+int ge_version(void) { return GE_VERSION; }
+
+int ge_max_dim(void) { return complex_max_dim(); }
+
+int ge_complex_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                     float max_norm, int apply_sigmoid, float* out, void* stream) {
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (B > 0 && (!triples || !out)) return GE_EINVAL;
+  return complex_score_launch(table, N, d, triples, B, max_norm, apply_sigmoid, out, (hipStream_t)stream);
+}
+
+int ge_hole_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                  float max_norm, int apply_sigmoid, float* out, void* stream) {
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (B > 0 && (!triples || !out)) return GE_EINVAL;
+  return hole_score_launch(table, N, d, triples, B, max_norm, apply_sigmoid, out, (hipStream_t)stream);
+}
+
+int ge_hinge_loss(const float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                  int64_t B, float margin, float max_norm, int model, float* loss, float* sig_out,
+                  void* stream) {
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm) || (model != 0 && model != 1)) return GE_EINVAL;
+  if (B > 0 && (!pos || !neg || !loss)) return GE_EINVAL;
+  if (model == 0)
+    return complex_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream);
+  return hole_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream);
+}
+
+int ge_hinge_grad(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                  int64_t B, float margin, float lr, float max_norm, int model, float* loss,
+                  int32_t* grad_idx, float* grad_val, void* stream) {
+  if (B < 0 || !ok_table(rows, N, d) || !max_norm_ok(max_norm) || (model != 0 && model != 1)) return GE_EINVAL;
+  if (B > 0 && (!pos || !neg || !loss || !grad_idx || !grad_val)) return GE_EINVAL;
+  if (model == 0)
+    return complex_hinge_grad_launch(rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, (hipStream_t)stream);
+  return hole_hinge_grad_launch(rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, (hipStream_t)stream);
+}
+
+int ge_scatter_add_rows(float* table, int64_t N, int32_t d, const int32_t* idx, const float* val,
+                        int64_t R, void* stream) {
+  if (R < 0 || !ok_table(table, N, d)) return GE_EINVAL;
+  if (R > 0 && (!idx || !val)) return GE_EINVAL;
+  return scatter_add_rows_launch(table, N, d, idx, val, R, (hipStream_t)stream);
+}
+
+int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx, int64_t R, float* out,
+                   void* stream) {
+  if (R < 0 || !ok_table(table, N, d)) return GE_EINVAL;
+  if (R > 0 && (!idx || !out)) return GE_EINVAL;
+  return gather_rows_launch(table, N, d, idx, R, out, (hipStream_t)stream);
+}
+
+// workspace layout: [grad_idx: 6B int32, padded to 256 B][grad_val: 6B*d fp32]
+size_t ge_hinge_step_workspace_bytes(int64_t B, int32_t d) {
+  if (B <= 0 || d <= 0) return 0;
+  return align_up(sizeof(int32_t) * 6 * (size_t)B, 256) + sizeof(float) * 6 * (size_t)B * (size_t)d;
+}
+
+static int hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg, int64_t B,
+                      float margin, float lr, float max_norm, int model, float* loss, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (B == 0) return 0;
+  if (!pos || !neg || !loss || !workspace) return GE_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
+  if (workspace_bytes < ge_hinge_step_workspace_bytes(B, d)) return GE_ENOMEM;
+  int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
+  float* gval = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(sizeof(int32_t) * 6 * (size_t)B, 256));
+  int rc = ge_hinge_grad(table, N, d, pos, neg, B, margin, lr, max_norm, model, loss, gidx, gval, stream);
+  if (rc != 0) return rc;
+  return scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, (hipStream_t)stream);
+}
+
+int ge_complex_hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                          int64_t B, float margin, float lr, float max_norm, float* loss, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  return hinge_step(table, N, d, pos, neg, B, margin, lr, max_norm, 0, loss, workspace, workspace_bytes, stream);
+}
+
+int ge_hole_hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                       int64_t B, float margin, float lr, float max_norm, float* loss, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  return hinge_step(table, N, d, pos, neg, B, margin, lr, max_norm, 1, loss, workspace, workspace_bytes, stream);
+}
+
+int ge_corrupt_batch(const int32_t* pos, int64_t B, const int32_t* id_to_type, int64_t N,
+                     const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids, uint64_t seed,
+                     uint64_t step, int32_t padded_size, int32_t mode, int32_t* neg, void* stream) {
+  if (B < 0 || N <= 0 || !id_to_type || !type_offsets || !type_ids) return GE_EINVAL;
+  if (B > 0 && (!pos || !neg)) return GE_EINVAL;
+  return corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, step,
+                              padded_size, mode, neg, (hipStream_t)stream);
+}
+
+int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
+                         const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid, int cand_is_head,
+                         float* out, void* stream) {
+  if (B < 0 || K < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm) || (d & 1)) return GE_EINVAL;
+  if (B > 0 && K > 0 && (!hr || !cand || !out)) return GE_EINVAL;
+  return complex_score_1vK_launch(table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out,
+                                  (hipStream_t)stream);
+}
+
+int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,
+                   int64_t B, int64_t n_steps, const int32_t* id_to_type, const int64_t* type_offsets,
+                   int32_t n_types, const int32_t* type_ids, uint64_t seed, uint64_t global_step0,
+                   int32_t padded_size, int32_t mode, float margin, float lr0, float decay_steps,
+                   float decay_rate, float max_norm, int model, float* loss, int keep_all_losses,
+                   int32_t* neg_ws, void* workspace, size_t workspace_bytes, void** ev_pairs, int ev_kernel,
+                   void* stream) {
+  if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm))
+    return GE_EINVAL;
+  if (!triples || !id_to_type || !type_offsets || !type_ids || !loss || !neg_ws || !workspace) return GE_EINVAL;
+  if (model != 0 && model != 1) return GE_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
+  if (workspace_bytes < ge_hinge_step_workspace_bytes(B, d)) return GE_ENOMEM;
+  if (ev_pairs && (ev_kernel < 0 || ev_kernel > 2)) return GE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
+  float* gval = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(sizeof(int32_t) * 6 * (size_t)B, 256));
+  int64_t row = first_row % T;
+  for (int64_t s = 0; s < n_steps; ++s) {
+    if (row + B > T) row = 0;  // never a short batch (holE.py:283)
+    const int32_t* pos = triples + 3 * row;
+    const uint64_t gs = global_step0 + (uint64_t)s;
+    const float lr = decay_steps > 0.f ? lr0 / (1.0f + decay_rate * ((float)gs / decay_steps)) : lr0;
+    float* loss_s = keep_all_losses ? loss + s * B : loss;
+    hipEvent_t e0 = ev_pairs ? (hipEvent_t)ev_pairs[2 * s] : nullptr;
+    hipEvent_t e1 = ev_pairs ? (hipEvent_t)ev_pairs[2 * s + 1] : nullptr;
+    int rc;
+    if (e0 && ev_kernel == 0) (void)hipEventRecord(e0, st);
+    rc = corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, gs, padded_size,
+                              mode, neg_ws, st);
+    if (e1 && ev_kernel == 0) (void)hipEventRecord(e1, st);
+    if (rc) return rc;
+    if (e0 && ev_kernel == 1) (void)hipEventRecord(e0, st);
+    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg_ws, B, margin, lr, max_norm, loss_s, gidx, gval, st)
+                    : hole_hinge_grad_launch(table, N, d, pos, neg_ws, B, margin, lr, max_norm, loss_s, gidx, gval, st);
+    if (e1 && ev_kernel == 1) (void)hipEventRecord(e1, st);
+    if (rc) return rc;
+    if (e0 && ev_kernel == 2) (void)hipEventRecord(e0, st);
+    rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st);
+    if (e1 && ev_kernel == 2) (void)hipEventRecord(e1, st);
+    if (rc) return rc;
+    row += B;
+  }
+  return 0;
+}
+
+int ge_event_create(void** ev) {
+  if (!ev) return GE_EINVAL;
+  hipEvent_t e;
+  hipError_t rc = hipEventCreate(&e);
+  if (rc != hipSuccess) return (int)rc;
+  *ev = (void*)e;
+  return 0;
+}
+int ge_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : GE_EINVAL; }
+int ge_event_record(void* ev, void* stream) { return ev ? (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) : GE_EINVAL; }
+int ge_event_synchronize(void* ev) { return ev ? (int)hipEventSynchronize((hipEvent_t)ev) : GE_EINVAL; }
+int ge_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return GE_EINVAL;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+
+}  // extern "C"

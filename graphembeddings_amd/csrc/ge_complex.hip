@@ -1,0 +1,356 @@
+// ge_complex.hip -- fused gather -> clip -> ComplEx score -> sigmoid -> hinge -> row-gradient kernels.
+//
+// Reference path replaced (all of it stock TF ops on CPU in the reference):
+//   get_embedding      holE.py:161-168   (Gather, clip_by_norm chain graph.pbtxt:3108-3596, Complex)
+//   evaluate_triples   holE.py:179-198   (Mul, Conj, Real, Sum, Sigmoid)
+//   evaluate_batch     holE.py:222-234   (Maximum)
+//   minimize()         holE.py:296       (autodiff of SUM(loss) -> IndexedSlices -> ScatterSub)
+//
+// Work decomposition (CDNA4): a group of LPT lanes (16/32/64, a power-of-two slice of one 64-lane
+// wavefront) owns one triple / one (pos,neg) pair.  Lane `sub` of the group holds VEC consecutive
+// real parts and the VEC matching imaginary parts of every row (row layout [Re(d/2) | Im(d/2)],
+// holE.py:164-166), so each row is read with two fully coalesced 16-byte-per-lane loads
+// (d=200: 25 lanes x 16 B = 400 B per half row) and the complex arithmetic is lane-local.
+// Norms and the score are reduced across the group with wave shuffles; nothing goes through LDS.
+// The clip is a per-row scalar and the score is trilinear, so s = sh*st*sr*s_raw and, by Euler's
+// identity for a trilinear form, (d s/d y_X) . x_X = s / scale_X: the backward pass through the
+// clip needs no reduction beyond the forward ones.
+#include "ge_common.h"
+
+namespace ge {
+
+template <int VEC, int NITER>
+struct Row {
+  float re[NITER][VEC];
+  float im[NITER][VEC];
+};
+
+template <int VEC, int LPT, int NITER>
+__device__ __forceinline__ void load_row(const float* __restrict__ rows, int32_t id, int d, int k,
+                                         int nvec, int sub, Row<VEC, NITER>& R) {
+  const float* p = rows + (int64_t)id * d;
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const int j = sub + it * LPT;
+    if (j < nvec) {
+      load_vec<VEC>(p + j * VEC, R.re[it]);
+      load_vec<VEC>(p + k + j * VEC, R.im[it]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { R.re[it][v] = 0.f; R.im[it][v] = 0.f; }
+    }
+  }
+}
+
+template <int VEC, int NITER>
+__device__ __forceinline__ float row_sumsq(const Row<VEC, NITER>& R) {
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < NITER; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ss += R.re[it][v] * R.re[it][v] + R.im[it][v] * R.im[it][v];
+  return ss;
+}
+
+// lane-partial of sum_k Re(h_k r_k conj(t_k)) = a(ce+df) + b(cf-de)   (holE.py:191-192)
+template <int VEC, int NITER>
+__device__ __forceinline__ float raw_score(const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
+                                           const Row<VEC, NITER>& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NITER; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float a = h.re[it][v], b = h.im[it][v], e = t.re[it][v], f = t.im[it][v];
+      const float c = r.re[it][v], dd = r.im[it][v];
+      s += a * (c * e + dd * f) + b * (c * f - dd * e);
+    }
+  return s;
+}
+
+struct SideFwd {
+  float s_raw;             // score of the un-clipped rows
+  float sc[3];             // clip scales h,t,r
+  float inv[3];            // rsqrt(sum x^2) h,t,r
+  float sig;               // sigma(s)
+  float s;                 // clipped score
+};
+
+template <int VEC, int LPT, int NITER>
+__device__ __forceinline__ SideFwd side_forward(const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
+                                                const Row<VEC, NITER>& r, float max_norm) {
+  SideFwd o;
+  const float ssh = group_sum<LPT>(row_sumsq(h));
+  const float sst = group_sum<LPT>(row_sumsq(t));
+  const float ssr = group_sum<LPT>(row_sumsq(r));
+  o.s_raw = group_sum<LPT>(raw_score(h, t, r));
+  o.sc[0] = clip_scale(ssh, max_norm, o.inv[0]);
+  o.sc[1] = clip_scale(sst, max_norm, o.inv[1]);
+  o.sc[2] = clip_scale(ssr, max_norm, o.inv[2]);
+  o.s = o.s_raw * o.sc[0] * o.sc[1] * o.sc[2];
+  o.sig = sigmoidf_dev(o.s);
+  return o;
+}
+
+__device__ __forceinline__ bool bad3(int64_t N, int32_t a, int32_t b, int32_t c) {
+  return a < 0 || b < 0 || c < 0 || a >= N || b >= N || c >= N;
+}
+
+// ---------------------------------------------------------------- evaluate_triples
+template <int VEC, int LPT, int NITER>
+__global__ __launch_bounds__(kBlock) void complex_score_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ triples, int64_t B,
+    float max_norm, int apply_sigmoid, float* __restrict__ out) {
+  constexpr int GPW = kWave / LPT;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int k = d >> 1, nvec = k / VEC;
+  for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
+    const int64_t g = base + grp;
+    const bool live = g < B;
+    int32_t hi = 0, ti = 0, ri = 0;
+    if (live) { hi = triples[3 * g]; ti = triples[3 * g + 1]; ri = triples[3 * g + 2]; }
+    const bool bad = bad3(N, hi, ti, ri);
+    if (bad) { hi = ti = ri = 0; }
+    Row<VEC, NITER> h, t, r;
+    load_row<VEC, LPT, NITER>(table, hi, d, k, nvec, sub, h);
+    load_row<VEC, LPT, NITER>(table, ti, d, k, nvec, sub, t);
+    load_row<VEC, LPT, NITER>(table, ri, d, k, nvec, sub, r);
+    const SideFwd f = side_forward<VEC, LPT, NITER>(h, t, r, max_norm);
+    if (live && sub == 0) out[g] = bad ? __builtin_nanf("") : (apply_sigmoid ? f.sig : f.s);
+  }
+}
+
+// ---------------------------------------------------------------- evaluate_batch (forward only)
+template <int VEC, int LPT, int NITER>
+__global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int64_t B, float margin, float max_norm,
+    float* __restrict__ loss, float* __restrict__ sig_out) {
+  constexpr int GPW = kWave / LPT;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int k = d >> 1, nvec = k / VEC;
+  for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
+    const int64_t g = base + grp;
+    const bool live = g < B;
+    int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+    }
+    const bool bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
+    if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    Row<VEC, NITER> h, t, r;
+    load_row<VEC, LPT, NITER>(table, p[0], d, k, nvec, sub, h);
+    load_row<VEC, LPT, NITER>(table, p[1], d, k, nvec, sub, t);
+    load_row<VEC, LPT, NITER>(table, p[2], d, k, nvec, sub, r);
+    const SideFwd fp = side_forward<VEC, LPT, NITER>(h, t, r, max_norm);
+    load_row<VEC, LPT, NITER>(table, n[0], d, k, nvec, sub, h);
+    load_row<VEC, LPT, NITER>(table, n[1], d, k, nvec, sub, t);
+    load_row<VEC, LPT, NITER>(table, n[2], d, k, nvec, sub, r);
+    const SideFwd fn = side_forward<VEC, LPT, NITER>(h, t, r, max_norm);
+    if (live && sub == 0) {
+      const float nanv = __builtin_nanf("");
+      loss[g] = bad ? nanv : fmaxf(fp.sig - fn.sig + margin, 0.f);  // holE.py:231
+      if (sig_out) { sig_out[g] = bad ? nanv : fp.sig; sig_out[B + g] = bad ? nanv : fn.sig; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- hinge + row gradients
+// d(sum_i L_i)/d(raw rows), pre-multiplied by -lr, as IndexedSlices (6 slots per pair:
+// h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
+// rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
+// Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
+struct RowCoef { float alpha, beta; };
+
+__device__ __forceinline__ RowCoef row_coef(float coef, const SideFwd& f, int X, float max_norm,
+                                            float neg_lr) {
+  const float P = (X == 0 ? f.sc[1] * f.sc[2] : X == 1 ? f.sc[0] * f.sc[2] : f.sc[0] * f.sc[1]);
+  const float A = coef * P;
+  const float inv = f.inv[X];
+  const bool active = inv <= 1.0f / max_norm;
+  RowCoef c;
+  c.alpha = neg_lr * (active ? max_norm * A * inv : A);
+  c.beta = active ? neg_lr * (-max_norm * A * f.s_raw * inv * inv * inv) : 0.f;
+  return c;
+}
+
+// raw bilinear gradients of s_raw wrt X for one lane slice
+template <int VEC, int NITER>
+__device__ __forceinline__ void graw(int X, const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
+                                     const Row<VEC, NITER>& r, int it, int v, float& gre, float& gim) {
+  const float a = h.re[it][v], b = h.im[it][v], e = t.re[it][v], f = t.im[it][v];
+  const float c = r.re[it][v], dd = r.im[it][v];
+  if (X == 0) { gre = c * e + dd * f; gim = c * f - dd * e; }        // d/dh
+  else if (X == 1) { gre = a * c - b * dd; gim = a * dd + b * c; }   // d/dt
+  else { gre = a * e + b * f; gim = a * f - b * e; }                 // d/dr
+}
+
+template <int VEC, int LPT, int NITER>
+__global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
+    const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
+    float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val) {
+  constexpr int GPW = kWave / LPT;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int k = d >> 1, nvec = k / VEC;
+  const float neg_lr = -lr;
+  for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
+    const int64_t g = base + grp;
+    const bool live = g < B;
+    int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+    }
+    const bool bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
+    if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    Row<VEC, NITER> xp[3], xn[3];
+#pragma unroll
+    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, xp[X]);
+#pragma unroll
+    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, n[X], d, k, nvec, sub, xn[X]);
+    const SideFwd fp = side_forward<VEC, LPT, NITER>(xp[0], xp[1], xp[2], max_norm);
+    const SideFwd fn = side_forward<VEC, LPT, NITER>(xn[0], xn[1], xn[2], max_norm);
+    const float pre = fp.sig - fn.sig + margin;
+    const bool on = live && !bad && (pre >= 0.f);  // MaximumGrad: x >= y
+    if (live && sub == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
+    const float cp = fp.sig * (1.f - fp.sig), cn = -fn.sig * (1.f - fn.sig);
+#pragma unroll
+    for (int X = 0; X < 3; ++X) {
+      const bool same = p[X] == n[X];
+      const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
+      if (live && sub == 0) {
+        grad_idx[rowP] = on ? p[X] : -1;
+        grad_idx[rowN] = (on && !same) ? n[X] : -1;
+      }
+      if (!on) continue;
+      const RowCoef kp = row_coef(cp, fp, X, max_norm, neg_lr);
+      const RowCoef kn = row_coef(cn, fn, X, max_norm, neg_lr);
+      float* gp = grad_val + rowP * d;
+      float* gn = grad_val + rowN * d;
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        const int j = sub + it * LPT;
+        if (j >= nvec) continue;
+        float pre_[VEC], pim_[VEC], nre_[VEC], nim_[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float gre, gim;
+          graw<VEC, NITER>(X, xp[0], xp[1], xp[2], it, v, gre, gim);
+          pre_[v] = kp.alpha * gre + kp.beta * xp[X].re[it][v];
+          pim_[v] = kp.alpha * gim + kp.beta * xp[X].im[it][v];
+          graw<VEC, NITER>(X, xn[0], xn[1], xn[2], it, v, gre, gim);
+          nre_[v] = kn.alpha * gre + kn.beta * xn[X].re[it][v];
+          nim_[v] = kn.alpha * gim + kn.beta * xn[X].im[it][v];
+        }
+        if (same) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { pre_[v] += nre_[v]; pim_[v] += nim_[v]; }
+          store_vec<VEC>(gp + j * VEC, pre_);
+          store_vec<VEC>(gp + k + j * VEC, pim_);
+        } else {
+          store_vec<VEC>(gp + j * VEC, pre_);
+          store_vec<VEC>(gp + k + j * VEC, pim_);
+          store_vec<VEC>(gn + j * VEC, nre_);
+          store_vec<VEC>(gn + k + j * VEC, nim_);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- dispatch
+struct Shape { int vec, lpt, niter; };
+
+static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
+  if (d <= 0 || (d & 1)) return false;
+  const int k = d / 2;
+  int vec = (k % 4 == 0) ? 4 : (k % 2 == 0) ? 2 : 1;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+  while (vec > 1 && (a % (vec * 4)) != 0) vec >>= 1;
+  const int nvec = k / vec;
+  int lpt = 16;
+  while (lpt < 64 && lpt < nvec) lpt <<= 1;
+  int niter = (nvec + lpt - 1) / lpt;
+  if (niter > 2) niter = 4;
+  if (niter > max_niter) return false;
+  s = {vec, lpt, niter};
+  return true;
+}
+
+#define GE_DISPATCH_SHAPE(S, MAXN, CALL)                                               \
+  do {                                                                                 \
+    const int key_ = (S).vec * 1000 + (S).lpt * 10 + (S).niter;                        \
+    switch (key_) {                                                                    \
+      case 1161: { CALL(1, 16, 1); } break;                                            \
+      case 1321: { CALL(1, 32, 1); } break;                                            \
+      case 1641: { CALL(1, 64, 1); } break;                                            \
+      case 1642: { CALL(1, 64, 2); } break;                                            \
+      case 2161: { CALL(2, 16, 1); } break;                                            \
+      case 2321: { CALL(2, 32, 1); } break;                                            \
+      case 2641: { CALL(2, 64, 1); } break;                                            \
+      case 2642: { CALL(2, 64, 2); } break;                                            \
+      case 4161: { CALL(4, 16, 1); } break;                                            \
+      case 4321: { CALL(4, 32, 1); } break;                                            \
+      case 4641: { CALL(4, 64, 1); } break;                                            \
+      case 4642: { CALL(4, 64, 2); } break;                                            \
+      default: return GE_ENOTSUP;                                                      \
+    }                                                                                  \
+  } while (0)
+
+int complex_score_launch(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                         float max_norm, int apply_sigmoid, float* out, hipStream_t st) {
+  Shape s;
+  if (!pick_shape(d, table, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
+  if (B == 0) return 0;
+  const int gpb = (kBlock / kWave) * (kWave / s.lpt);
+  const int grid = grid_for(B, gpb);
+#define CALL(V, L, NI) \
+  hipLaunchKernelGGL((complex_score_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out)
+  GE_DISPATCH_SHAPE(s, 2, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int complex_hinge_loss_launch(const float* table, int64_t N, int32_t d, const int32_t* pos,
+                              const int32_t* neg, int64_t B, float margin, float max_norm, float* loss,
+                              float* sig_out, hipStream_t st) {
+  Shape s;
+  if (!pick_shape(d, table, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
+  if (B == 0) return 0;
+  const int gpb = (kBlock / kWave) * (kWave / s.lpt);
+  const int grid = grid_for(B, gpb);
+#define CALL(V, L, NI) \
+  hipLaunchKernelGGL((complex_hinge_loss_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, pos, neg, B, margin, max_norm, loss, sig_out)
+  GE_DISPATCH_SHAPE(s, 2, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos,
+                              const int32_t* neg, int64_t B, float margin, float lr, float max_norm,
+                              float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st) {
+  Shape s;
+  if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
+  // the gradient rows are written with the same vector width: grad_val must be as aligned as rows
+  while (s.vec > 1 && (reinterpret_cast<uintptr_t>(grad_val) % (s.vec * 4)) != 0) return GE_EINVAL;
+  if (B == 0) return 0;
+  const int gpb = (kBlock / kWave) * (kWave / s.lpt);
+  const int grid = grid_for(B, gpb);
+#define CALL(V, L, NI) \
+  hipLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val)
+  GE_DISPATCH_SHAPE(s, 2, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int complex_max_dim() { return 4 * 64 * 2 * 2; }  // VEC*LPT*NITER complex dims * 2
+
+}  // namespace ge

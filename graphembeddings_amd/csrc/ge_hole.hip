@@ -1,0 +1,295 @@
+// ge_hole.hip -- HolE (holographic embeddings) score / hinge / row gradients.
+//
+// Score of README.md:42:  E(h,t,r) = sigmoid( r . (h star t) ),
+//   (h star t)_k = sum_i h_i t_{(i+k) mod d}  ( = ifft(conj(fft(h)) fft(t)) ).
+// The current holE.py computes ComplEx (holE.py:191-192); its circular_correlation helper
+// (holE.py:175-176) is dead code, so the README formula is the contract.  Rows are clipped as in
+// get_embedding (holE.py:162) and the score is squashed by the same sigmoid (holE.py:198).
+//
+// Kernel design (CDNA4): one 64-lane wavefront per triple.  Rows are staged in LDS; the "b" operand
+// of a correlation is stored doubled (b[j] = x[j mod d]) so no modulo is needed in the inner loop.
+// Lane l owns the 4 consecutive lags k = 256*c + 4*l .. +3 and walks i in steps of 4: per step one
+// broadcast ds_read_b128 of a[i..i+3] and two conflict-free ds_read_b128 of b[i+k .. i+k+7] feed
+// 16 FMAs (3 LDS instructions per 16 FMAs, register-blocked 4x4).  d=200 is not a power of two
+// and needs no padding beyond rounding to a multiple of 4.
+// The gradients are three more correlations of the same shape:
+//   ds/dr_m = (h star t)_m     ds/dh_m = (r star t)_m     ds/dt_m = (rev(r) star h)_m,
+// with rev(r)_i = r_{(-i) mod d}  (so that sum_k r_k h_{(m-k)} becomes a correlation).
+#include "ge_common.h"
+
+namespace ge {
+
+struct HoleFwd {
+  float s_raw, s, sig;
+  float sc[3], inv[3];
+};
+
+// 4 lags per lane per chunk: c[q] += sum_i a[i] * b[i + k0 + q]
+__device__ __forceinline__ void corr4(const float* __restrict__ a, const float* __restrict__ b, int d4,
+                                      int k0, float (&c)[4]) {
+  c[0] = c[1] = c[2] = c[3] = 0.f;
+  const float* bk = b + k0;
+  for (int i = 0; i < d4; i += 4) {
+    const float4 av = *reinterpret_cast<const float4*>(a + i);
+    const float4 b0 = *reinterpret_cast<const float4*>(bk + i);
+    const float4 b1 = *reinterpret_cast<const float4*>(bk + i + 4);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float aa[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] += aa[u] * bb[u + q];
+  }
+}
+
+// Stage one triple's rows in this wave's LDS slice and run the correlations.
+// LDS slice layout (floats): a_h[d4] a_r[d4] a_rr[d4] b_t[LB] b_h[LB],  LB = d4 + NCH*256.
+template <int NCH, bool GRAD>
+__device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d, int d4,
+                                          const int32_t (&id)[3], float* __restrict__ lds, int lane,
+                                          float max_norm, HoleFwd& f, float (&Gr)[NCH][4],
+                                          float (&Gh)[NCH][4], float (&Gt)[NCH][4]) {
+  const int LB = d4 + NCH * 256;
+  float* a_h = lds;
+  float* a_r = a_h + d4;
+  float* a_rr = a_r + d4;
+  float* b_t = a_rr + d4;
+  float* b_h = b_t + LB;
+  const float* xh = rows + (int64_t)id[0] * d;
+  const float* xt = rows + (int64_t)id[1] * d;
+  const float* xr = rows + (int64_t)id[2] * d;
+  float ssh = 0.f, sst = 0.f, ssr = 0.f;
+  for (int j = lane; j < d4; j += kWave) {
+    const bool in = j < d;
+    const float vh = in ? xh[j] : 0.f, vr = in ? xr[j] : 0.f, vt = in ? xt[j] : 0.f;
+    a_h[j] = vh;
+    a_r[j] = vr;
+    if (GRAD) a_rr[j] = in ? xr[j == 0 ? 0 : d - j] : 0.f;
+    ssh += vh * vh; ssr += vr * vr; sst += vt * vt;
+  }
+  for (int j = lane; j < LB; j += kWave) {
+    int jm = j;
+    while (jm >= d) jm -= d;
+    b_t[j] = xt[jm];
+    if (GRAD) b_h[j] = xh[jm];
+  }
+  __syncthreads();
+  float part = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k0 = c * 256 + 4 * lane;
+    if (k0 < d4) {
+      corr4(a_h, b_t, d4, k0, Gr[c]);  // (h star t): d s/d r, and the score itself
+      const float4 rv = *reinterpret_cast<const float4*>(a_r + k0);
+      part += rv.x * Gr[c][0] + rv.y * Gr[c][1] + rv.z * Gr[c][2] + rv.w * Gr[c][3];
+      if (GRAD) {
+        corr4(a_r, b_t, d4, k0, Gh[c]);   // (r star t): d s/d h
+        corr4(a_rr, b_h, d4, k0, Gt[c]);  // (rev r star h): d s/d t
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { Gr[c][q] = 0.f; Gh[c][q] = 0.f; Gt[c][q] = 0.f; }
+    }
+  }
+  f.s_raw = group_sum<kWave>(part);
+  ssh = group_sum<kWave>(ssh); sst = group_sum<kWave>(sst); ssr = group_sum<kWave>(ssr);
+  f.sc[0] = clip_scale(ssh, max_norm, f.inv[0]);
+  f.sc[1] = clip_scale(sst, max_norm, f.inv[1]);
+  f.sc[2] = clip_scale(ssr, max_norm, f.inv[2]);
+  f.s = f.s_raw * f.sc[0] * f.sc[1] * f.sc[2];
+  f.sig = sigmoidf_dev(f.s);
+  __syncthreads();  // LDS slice is reused by the next side / next triple
+}
+
+__device__ __forceinline__ bool hbad3(int64_t N, const int32_t (&t)[3]) {
+  return t[0] < 0 || t[1] < 0 || t[2] < 0 || t[0] >= N || t[1] >= N || t[2] >= N;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void hole_score_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ triples, int64_t B,
+    float max_norm, int apply_sigmoid, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d4 = (d + 3) & ~3;
+  const int per_wave = 3 * d4 + 2 * (d4 + NCH * 256);
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+  float* lds = smem + w * per_wave;
+  constexpr int WPB = kBlock / kWave;
+  for (int64_t base = (int64_t)blockIdx.x * WPB; base < B; base += (int64_t)gridDim.x * WPB) {
+    const int64_t g = base + w;
+    const bool live = g < B;
+    int32_t id[3] = {0, 0, 0};
+    if (live) { id[0] = triples[3 * g]; id[1] = triples[3 * g + 1]; id[2] = triples[3 * g + 2]; }
+    const bool bad = hbad3(N, id);
+    if (bad) { id[0] = id[1] = id[2] = 0; }
+    HoleFwd f;
+    float Gr[NCH][4], Gh[NCH][4], Gt[NCH][4];
+    hole_side<NCH, false>(table, d, d4, id, lds, lane, max_norm, f, Gr, Gh, Gt);
+    if (live && lane == 0) out[g] = bad ? __builtin_nanf("") : (apply_sigmoid ? f.sig : f.s);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void hole_hinge_loss_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int64_t B, float margin, float max_norm,
+    float* __restrict__ loss, float* __restrict__ sig_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d4 = (d + 3) & ~3;
+  const int per_wave = 3 * d4 + 2 * (d4 + NCH * 256);
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+  float* lds = smem + w * per_wave;
+  constexpr int WPB = kBlock / kWave;
+  for (int64_t base = (int64_t)blockIdx.x * WPB; base < B; base += (int64_t)gridDim.x * WPB) {
+    const int64_t g = base + w;
+    const bool live = g < B;
+    int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+    }
+    const bool bad = hbad3(N, p) || hbad3(N, n);
+    if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    HoleFwd fp, fn;
+    float Gr[NCH][4], Gh[NCH][4], Gt[NCH][4];
+    hole_side<NCH, false>(table, d, d4, p, lds, lane, max_norm, fp, Gr, Gh, Gt);
+    hole_side<NCH, false>(table, d, d4, n, lds, lane, max_norm, fn, Gr, Gh, Gt);
+    if (live && lane == 0) {
+      const float nanv = __builtin_nanf("");
+      loss[g] = bad ? nanv : fmaxf(fp.sig - fn.sig + margin, 0.f);
+      if (sig_out) { sig_out[g] = bad ? nanv : fp.sig; sig_out[B + g] = bad ? nanv : fn.sig; }
+    }
+  }
+}
+
+struct HCoef { float alpha, beta; };
+__device__ __forceinline__ HCoef hole_coef(float coef, const HoleFwd& f, int X, float max_norm, float neg_lr) {
+  const float P = (X == 0 ? f.sc[1] * f.sc[2] : X == 1 ? f.sc[0] * f.sc[2] : f.sc[0] * f.sc[1]);
+  const float A = coef * P;
+  const float inv = f.inv[X];
+  const bool active = inv <= 1.0f / max_norm;  // MinimumGrad routes to the rsqrt branch
+  HCoef c;
+  c.alpha = neg_lr * (active ? max_norm * A * inv : A);
+  c.beta = active ? neg_lr * (-max_norm * A * f.s_raw * inv * inv * inv) : 0.f;
+  return c;
+}
+
+// IndexedSlices of d(sum_i L_i)/d(rows) * (-lr); slot order h+, t+, r+, h-, t-, r- (see ge_hip.h).
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void hole_hinge_grad_kernel(
+    const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
+    float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d4 = (d + 3) & ~3;
+  const int per_wave = 3 * d4 + 2 * (d4 + NCH * 256);
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+  float* lds = smem + w * per_wave;
+  constexpr int WPB = kBlock / kWave;
+  const float neg_lr = -lr;
+  for (int64_t base = (int64_t)blockIdx.x * WPB; base < B; base += (int64_t)gridDim.x * WPB) {
+    const int64_t g = base + w;
+    const bool live = g < B;
+    int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+    }
+    const bool bad = hbad3(N, p) || hbad3(N, n);
+    if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    HoleFwd fp, fn;
+    // G[side][X]: X = 0 h, 1 t, 2 r
+    float GP[3][NCH][4], GN[3][NCH][4];
+    hole_side<NCH, true>(rows, d, d4, p, lds, lane, max_norm, fp, GP[2], GP[0], GP[1]);
+    hole_side<NCH, true>(rows, d, d4, n, lds, lane, max_norm, fn, GN[2], GN[0], GN[1]);
+    const float pre = fp.sig - fn.sig + margin;
+    const bool on = live && !bad && (pre >= 0.f);
+    if (live && lane == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
+    const float cp = fp.sig * (1.f - fp.sig), cn = -fn.sig * (1.f - fn.sig);
+#pragma unroll
+    for (int X = 0; X < 3; ++X) {
+      const bool same = p[X] == n[X];
+      const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
+      if (live && lane == 0) {
+        grad_idx[rowP] = on ? p[X] : -1;
+        grad_idx[rowN] = (on && !same) ? n[X] : -1;
+      }
+      if (!on) continue;
+      const HCoef kp = hole_coef(cp, fp, X, max_norm, neg_lr);
+      const HCoef kn = hole_coef(cn, fn, X, max_norm, neg_lr);
+      const float* xp = rows + (int64_t)p[X] * d;
+      const float* xn = rows + (int64_t)n[X] * d;
+      float* gp = grad_val + rowP * d;
+      float* gn = grad_val + rowN * d;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int k0 = c * 256 + 4 * lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = k0 + q;
+          if (kk >= d) continue;
+          const float vp = kp.alpha * GP[X][c][q] + kp.beta * xp[kk];
+          const float vn = kn.alpha * GN[X][c][q] + kn.beta * xn[kk];
+          if (same) gp[kk] = vp + vn;
+          else { gp[kk] = vp; gn[kk] = vn; }
+        }
+      }
+    }
+  }
+}
+
+static inline size_t hole_lds_bytes(int d, int nch) {
+  const int d4 = (d + 3) & ~3;
+  return sizeof(float) * (size_t)(kBlock / kWave) * (3 * d4 + 2 * (d4 + nch * 256));
+}
+
+int hole_max_dim() { return 512; }
+
+int hole_score_launch(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                      float max_norm, int apply_sigmoid, float* out, hipStream_t st) {
+  if (d <= 0) return GE_EINVAL;
+  if (d > hole_max_dim()) return GE_ENOTSUP;
+  if (B == 0) return 0;
+  const int nch = d <= 256 ? 1 : 2;
+  const int grid = grid_for(B, kBlock / kWave);
+  const size_t lds = hole_lds_bytes(d, nch);
+  if (nch == 1)
+    hipLaunchKernelGGL(hole_score_kernel<1>, dim3(grid), dim3(kBlock), lds, st, table, N, d, triples, B, max_norm, apply_sigmoid, out);
+  else
+    hipLaunchKernelGGL(hole_score_kernel<2>, dim3(grid), dim3(kBlock), lds, st, table, N, d, triples, B, max_norm, apply_sigmoid, out);
+  return launch_status();
+}
+
+int hole_hinge_loss_launch(const float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                           int64_t B, float margin, float max_norm, float* loss, float* sig_out,
+                           hipStream_t st) {
+  if (d <= 0) return GE_EINVAL;
+  if (d > hole_max_dim()) return GE_ENOTSUP;
+  if (B == 0) return 0;
+  const int nch = d <= 256 ? 1 : 2;
+  const int grid = grid_for(B, kBlock / kWave);
+  const size_t lds = hole_lds_bytes(d, nch);
+  if (nch == 1)
+    hipLaunchKernelGGL(hole_hinge_loss_kernel<1>, dim3(grid), dim3(kBlock), lds, st, table, N, d, pos, neg, B, margin, max_norm, loss, sig_out);
+  else
+    hipLaunchKernelGGL(hole_hinge_loss_kernel<2>, dim3(grid), dim3(kBlock), lds, st, table, N, d, pos, neg, B, margin, max_norm, loss, sig_out);
+  return launch_status();
+}
+
+int hole_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                           int64_t B, float margin, float lr, float max_norm, float* loss,
+                           int32_t* grad_idx, float* grad_val, hipStream_t st) {
+  if (d <= 0) return GE_EINVAL;
+  if (d > hole_max_dim()) return GE_ENOTSUP;
+  if (B == 0) return 0;
+  const int nch = d <= 256 ? 1 : 2;
+  const int grid = grid_for(B, kBlock / kWave);
+  const size_t lds = hole_lds_bytes(d, nch);
+  if (nch == 1)
+    hipLaunchKernelGGL(hole_hinge_grad_kernel<1>, dim3(grid), dim3(kBlock), lds, st, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val);
+  else
+    hipLaunchKernelGGL(hole_hinge_grad_kernel<2>, dim3(grid), dim3(kBlock), lds, st, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val);
+  return launch_status();
+}
+
+}  // namespace ge

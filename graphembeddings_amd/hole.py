@@ -1,0 +1,334 @@
+"""Host-side mirror of the holE.py operator interface for the hot path, on libge_hip.so.
+
+Same names, argument meaning and orientation as the reference functions (cited per function);
+tensors are PyTorch-ROCm CUDA tensors instead of TF graph nodes, and every call enqueues hand-written
+HIP kernels on torch's current stream through the C ABI of include/ge_hip.h.  PyTorch is plumbing
+here (device memory, streams); there is no torch / CPU compute fallback.
+
+Orientation reminder: E(h,t,r) = sigmoid(score) is a LOSS -- lower is more
+plausible; the hinge max(E(pos) - E(neg) + margin, 0) pushes positive scores down.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MODEL_COMPLEX, MODEL_HOLE = 0, 1
+_MODELS = {"complex": MODEL_COMPLEX, "hole": MODEL_HOLE, 0: 0, 1: 1}
+
+CORRUPT_BATCH_COIN, CORRUPT_ROW_COIN, CORRUPT_HEADS, CORRUPT_TAILS = 0, 1, 2, 3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, name: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: graphembeddings_amd has no CPU path")
+
+
+def _table(embeddings: torch.Tensor):
+    _need_cuda(embeddings, "embeddings")
+    if embeddings.dtype != torch.float32 or embeddings.dim() != 2 or not embeddings.is_contiguous():
+        raise ValueError("embeddings must be a contiguous float32 [entity_count, embedding_dim] tensor")
+    return embeddings
+
+
+def _triples(t: torch.Tensor, name="triple_batch") -> torch.Tensor:
+    """[B,3] (head, tail, relation) (holE.py:181-185). int64 accepted (holE.py:547) and narrowed."""
+    _need_cuda(t, name)
+    if t.dim() != 2 or t.shape[1] != 3:
+        raise ValueError(f"{name} must have shape [B, 3] (head, tail, relation)")
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t.contiguous()
+
+
+def init_embeddings(entity_count: int, embedding_dim: int, device="cuda", seed: Optional[int] = None):
+    """The `embeddings` variable of holE.py:263-264: xavier_initializer(uniform=False) =
+    truncated normal (re-drawn beyond 2 sigma) with stddev sqrt(2.6 / (entity_count + dim))."""
+    gen = torch.Generator(device="cpu")
+    if seed is not None:
+        gen.manual_seed(seed)
+    std = float(np.sqrt(2.6 / (entity_count + embedding_dim)))
+    t = torch.empty(entity_count, embedding_dim, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+    return t.to(device)
+
+
+def evaluate_triples(triple_batch: torch.Tensor, embeddings: torch.Tensor, label=None, *,
+                     model="complex", max_norm: float = 1.0, apply_sigmoid: bool = True) -> torch.Tensor:
+    """holE.py:179-202 (hinge / inference branch): sigmoid(sum_k Re(h_k r_k conj(t_k))) as [B,1].
+
+    `label` is accepted for signature compatibility; the log-loss branch (holE.py:194-196) is out of
+    scope and raises.  model="hole" gives the README.md:42 HolE score instead.
+    """
+    if label is not None:
+        raise NotImplementedError("log_loss mode (holE.py:194-196) is not part of this path")
+    emb = _table(embeddings)
+    tb = _triples(triple_batch)
+    out = torch.empty(tb.shape[0], dtype=torch.float32, device=emb.device)
+    fn = "ge_complex_score" if _MODELS[model] == MODEL_COMPLEX else "ge_hole_score"
+    _lib.call(fn, emb.data_ptr(), emb.shape[0], emb.shape[1], tb.data_ptr(), tb.shape[0],
+              max_norm, int(apply_sigmoid), out.data_ptr(), _stream())
+    return out.view(-1, 1)
+
+
+@dataclass
+class TypeTables:
+    """Device form of the two corruption tables of holE.py:267-277.
+
+    id_to_type : int32 [entity_count] type code per table row (-1 unknown -> '?' default, holE.py:39)
+    type_offsets / type_ids : CSR of type code -> ids (the full lists of data.type_to_ids; the
+    per-batch padded_size subsample of holE.py:343-347 is drawn inside the kernel).
+    """
+    id_to_type: torch.Tensor
+    type_offsets: torch.Tensor
+    type_ids: torch.Tensor
+    padded_size: int = 1024
+
+    @staticmethod
+    def from_host(id_to_type, type_offsets, type_ids, padded_size=1024, device="cuda") -> "TypeTables":
+        return TypeTables(
+            torch.as_tensor(np.ascontiguousarray(id_to_type, dtype=np.int32)).to(device),
+            torch.as_tensor(np.ascontiguousarray(type_offsets, dtype=np.int64)).to(device),
+            torch.as_tensor(np.ascontiguousarray(type_ids, dtype=np.int32)).to(device),
+            int(padded_size))
+
+    @property
+    def n_types(self) -> int:
+        return int(self.type_offsets.numel()) - 1
+
+
+def corrupt_batch(type_tables: TypeTables, relation_count: int, triples: torch.Tensor, *, seed: int = 0,
+                  step: int = 0, mode: int = CORRUPT_BATCH_COIN) -> torch.Tensor:
+    """holE.py:152-153 (-> corrupt_entities 136-140 -> corrupt_heads/tails 97-133): type-safe
+    corruption, [B,3] int32.  relation_count is unused, as in the reference (relation corruption is
+    commented out, holE.py:154-158).  (seed, step) key the counter-based random stream."""
+    tb = _triples(triples, "triples")
+    _need_cuda(type_tables.id_to_type, "type tables")
+    neg = torch.empty_like(tb)
+    _lib.call("ge_corrupt_batch", tb.data_ptr(), tb.shape[0], type_tables.id_to_type.data_ptr(),
+              type_tables.id_to_type.numel(), type_tables.type_offsets.data_ptr(), type_tables.n_types,
+              type_tables.type_ids.data_ptr(), int(seed) & (2**64 - 1), int(step) & (2**64 - 1),
+              type_tables.padded_size, int(mode), neg.data_ptr(), _stream())
+    return neg
+
+
+def hinge_loss(pos: torch.Tensor, neg: torch.Tensor, embeddings: torch.Tensor, *, margin: float = 0.2,
+               model="complex", max_norm: float = 1.0, return_sigmoids: bool = False):
+    """max(E(pos) - E(neg) + margin, 0) as [B,1] (holE.py:231) for given negatives."""
+    emb = _table(embeddings)
+    p, n = _triples(pos, "pos"), _triples(neg, "neg")
+    if p.shape != n.shape:
+        raise ValueError("pos and neg must have the same shape")
+    B = p.shape[0]
+    loss = torch.empty(B, dtype=torch.float32, device=emb.device)
+    sig = torch.empty(2 * B, dtype=torch.float32, device=emb.device) if return_sigmoids else None
+    _lib.call("ge_hinge_loss", emb.data_ptr(), emb.shape[0], emb.shape[1], p.data_ptr(), n.data_ptr(), B,
+              margin, max_norm, _MODELS[model], loss.data_ptr(), sig.data_ptr() if sig is not None else None,
+              _stream())
+    if return_sigmoids:
+        return loss.view(-1, 1), sig[:B].view(-1, 1), sig[B:].view(-1, 1)
+    return loss.view(-1, 1)
+
+
+def evaluate_batch(triple_batch: torch.Tensor, embeddings: torch.Tensor, type_to_ids_table: TypeTables,
+                   id_to_type_table=None, relation_count: int = 0, *, margin: float = 0.2,
+                   model="complex", seed: int = 0, step: int = 0, mode: int = CORRUPT_BATCH_COIN,
+                   max_norm: float = 1.0) -> torch.Tensor:
+    """holE.py:205-234 (hinge branch): corrupt the batch type-safely, score both, return the hinge
+    [B,1].  The reference passes two hash tables; here both live in one TypeTables object
+    (`id_to_type_table` is accepted and ignored)."""
+    neg = corrupt_batch(type_to_ids_table, relation_count, triple_batch, seed=seed, step=step, mode=mode)
+    return hinge_loss(triple_batch, neg, embeddings, margin=margin, model=model, max_norm=max_norm)
+
+
+def inverse_time_decay(learning_rate: float, global_step: int, decay_steps: float, decay_rate: float) -> float:
+    """tf.train.inverse_time_decay as called at holE.py:292-294 (no staircase)."""
+    return learning_rate / (1.0 + decay_rate * (float(global_step) / float(decay_steps)))
+
+
+class HingeSGD:
+    """GradientDescentOptimizer(lr).minimize(loss) of holE.py:296 for the hinge of holE.py:231,
+    fused on the GPU: gradient of SUM_i loss_i, then ScatterSub with duplicates accumulating.
+    Owns the scratch workspace the C ABI needs."""
+
+    def __init__(self, embeddings: torch.Tensor, batch_size: int, *, margin: float = 0.2,
+                 model="complex", max_norm: float = 1.0):
+        self.embeddings = _table(embeddings)
+        self.margin, self.max_norm = float(margin), float(max_norm)
+        self.model = _MODELS[model]
+        self._ws = None
+        self._reserve(batch_size)
+
+    def _reserve(self, B: int):
+        need = _lib.load().ge_hinge_step_workspace_bytes(B, self.embeddings.shape[1])
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.embeddings.device)
+
+    def step(self, pos: torch.Tensor, neg: torch.Tensor, lr: float) -> torch.Tensor:
+        """One training step in place on the table; returns the per-pair hinge [B,1]."""
+        emb = self.embeddings
+        p, n = _triples(pos, "pos"), _triples(neg, "neg")
+        if p.shape != n.shape:
+            raise ValueError("pos and neg must have the same shape")
+        B = p.shape[0]
+        self._reserve(B)
+        loss = torch.empty(B, dtype=torch.float32, device=emb.device)
+        fn = "ge_complex_hinge_step" if self.model == MODEL_COMPLEX else "ge_hole_hinge_step"
+        _lib.call(fn, emb.data_ptr(), emb.shape[0], emb.shape[1], p.data_ptr(), n.data_ptr(), B,
+                  self.margin, float(lr), self.max_norm, loss.data_ptr(), self._ws.data_ptr(),
+                  self._ws.numel(), _stream())
+        return loss.view(-1, 1)
+
+
+def hinge_grad(rows: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, lr: float, *, margin=0.2,
+               model="complex", max_norm=1.0):
+    """First half of the step (ge_hinge_grad): returns (loss [B], grad_idx [6B] int32, grad_val [6B,d])
+    with grad_val already multiplied by -lr.  `rows` may be a staging buffer of fetched rows."""
+    rows = _table(rows)
+    p, n = _triples(pos, "pos"), _triples(neg, "neg")
+    B, d = p.shape[0], rows.shape[1]
+    loss = torch.empty(B, dtype=torch.float32, device=rows.device)
+    gi = torch.empty(6 * B, dtype=torch.int32, device=rows.device)
+    gv = torch.empty(6 * B, d, dtype=torch.float32, device=rows.device)
+    _lib.call("ge_hinge_grad", rows.data_ptr(), rows.shape[0], d, p.data_ptr(), n.data_ptr(), B, margin,
+              float(lr), max_norm, _MODELS[model], loss.data_ptr(), gi.data_ptr(), gv.data_ptr(), _stream())
+    return loss, gi, gv
+
+
+def scatter_add_rows(table: torch.Tensor, idx: torch.Tensor, val: torch.Tensor) -> None:
+    """table[idx[i]] += val[i] for idx[i] >= 0 (ScatterSub with the sign folded into val)."""
+    table = _table(table)
+    _need_cuda(idx, "idx"); _need_cuda(val, "val")
+    idx = idx.to(torch.int32).contiguous()
+    val = val.to(torch.float32).contiguous()
+    if val.shape != (idx.numel(), table.shape[1]):
+        raise ValueError("val must be [len(idx), embedding_dim]")
+    _lib.call("ge_scatter_add_rows", table.data_ptr(), table.shape[0], table.shape[1], idx.data_ptr(),
+              val.data_ptr(), idx.numel(), _stream())
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[i] = table[idx[i]] (zeros where idx[i] < 0)."""
+    table = _table(table)
+    _need_cuda(idx, "idx")
+    idx = idx.to(torch.int32).contiguous()
+    out = torch.empty(idx.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+    _lib.call("ge_gather_rows", table.data_ptr(), table.shape[0], table.shape[1], idx.data_ptr(),
+              idx.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def score_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, candidates: torch.Tensor, *,
+                     cand_is_head: bool = False, max_norm: float = 1.0, apply_sigmoid: bool = True) -> torch.Tensor:
+    """The candidate sweep of holE.py:564-569 in one call: E for every (fixed_i, cand_j, rel_i)
+    (or (cand_j, fixed_i, rel_i) with cand_is_head) as [B,K]; fp32-MFMA GEMM on the GPU."""
+    emb = _table(embeddings)
+    _need_cuda(fixed_and_relation, "fixed_and_relation"); _need_cuda(candidates, "candidates")
+    hr = fixed_and_relation.to(torch.int32).contiguous()
+    cand = candidates.to(torch.int32).contiguous().view(-1)
+    if hr.dim() != 2 or hr.shape[1] != 2:
+        raise ValueError("fixed_and_relation must be [B,2] (entity, relation)")
+    out = torch.empty(hr.shape[0], cand.numel(), dtype=torch.float32, device=emb.device)
+    _lib.call("ge_complex_score_1vK", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), hr.shape[0],
+              cand.data_ptr(), cand.numel(), max_norm, int(apply_sigmoid), int(cand_is_head), out.data_ptr(),
+              _stream())
+    return out
+
+
+class Trainer:
+    """The inner loop of run_training (holE.py:340-362, minus validation) enqueued natively by
+    ge_train_steps: per step a batch of the device-resident shuffled triple array, type-safe
+    negatives, lr from inverse_time_decay, one fused hinge SGD step.  No host work per step."""
+
+    def __init__(self, embeddings: torch.Tensor, triples: torch.Tensor, type_tables: TypeTables,
+                 batch_size: int, *, margin: float = 0.2, learning_rate: float = 0.1,
+                 decay_steps: float = 0.0, decay_rate: float = 0.5, model="complex", max_norm: float = 1.0,
+                 seed: int = 0, corrupt_mode: int = CORRUPT_BATCH_COIN):
+        self.embeddings = _table(embeddings)
+        self.triples = _triples(triples, "triples")
+        if self.triples.shape[0] < batch_size:
+            raise ValueError("fewer triples than batch_size (the reference never yields a short batch)")
+        self.tt = type_tables
+        self.B = int(batch_size)
+        self.margin, self.lr0 = float(margin), float(learning_rate)
+        self.decay_steps, self.decay_rate = float(decay_steps), float(decay_rate)
+        self.model, self.max_norm, self.seed, self.mode = _MODELS[model], float(max_norm), int(seed), int(corrupt_mode)
+        self.global_step = 0
+        self.row = 0
+        dev = self.embeddings.device
+        need = _lib.load().ge_hinge_step_workspace_bytes(self.B, self.embeddings.shape[1])
+        self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        self._neg = torch.empty(self.B, 3, dtype=torch.int32, device=dev)
+        self.last_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)
+
+    def learning_rate(self, step=None) -> float:
+        s = self.global_step if step is None else step
+        return inverse_time_decay(self.lr0, s, self.decay_steps, self.decay_rate) if self.decay_steps > 0 else self.lr0
+
+    def reshuffle(self, generator=None):
+        """New pass order (the shuffle queue of holE.py:281-283), done on the device."""
+        perm = torch.randperm(self.triples.shape[0], device=self.triples.device, generator=generator)
+        self.triples = self.triples[perm].contiguous()
+        self.row = 0
+
+    def run(self, n_steps: int, *, keep_losses: bool = False, events=None, ev_kernel: int = 2):
+        """Enqueue n_steps training steps on the current stream; returns the loss tensor
+        ([n_steps,B] if keep_losses else the last step's [B])."""
+        import ctypes as C
+        emb, T = self.embeddings, self.triples.shape[0]
+        loss = (torch.empty(n_steps * self.B, dtype=torch.float32, device=emb.device)
+                if keep_losses else self.last_loss)
+        evp = None
+        if events is not None:
+            assert len(events) == 2 * n_steps
+            evp = (C.c_void_p * len(events))(*events)
+        _lib.call("ge_train_steps", emb.data_ptr(), emb.shape[0], emb.shape[1], self.triples.data_ptr(), T,
+                  self.row, self.B, n_steps, self.tt.id_to_type.data_ptr(), self.tt.type_offsets.data_ptr(),
+                  self.tt.n_types, self.tt.type_ids.data_ptr(), self.seed & (2**64 - 1), self.global_step,
+                  self.tt.padded_size, self.mode, self.margin, self.lr0, self.decay_steps, self.decay_rate,
+                  self.max_norm, self.model, loss.data_ptr(), int(keep_losses), self._neg.data_ptr(),
+                  self._ws.data_ptr(), self._ws.numel(), evp, int(ev_kernel), _stream())
+        # mirror the C loop's row bookkeeping
+        row = self.row % T
+        for _ in range(n_steps):
+            if row + self.B > T:
+                row = 0
+            row += self.B
+        self.row = row
+        self.global_step += n_steps
+        return loss.view(n_steps, self.B) if keep_losses else loss
+
+
+class Events:
+    """hipEvent_t handles from the C ABI (ge_event_*), recorded on the launch stream."""
+
+    def __init__(self, n: int):
+        import ctypes as C
+        self.handles = []
+        for _ in range(n):
+            h = C.c_void_p()
+            _lib.call("ge_event_create", C.byref(h))
+            self.handles.append(h.value)
+
+    def record(self, i: int):
+        _lib.call("ge_event_record", self.handles[i], _stream())
+
+    def elapsed_ms(self, i: int, j: int) -> float:
+        import ctypes as C
+        ms = C.c_float()
+        _lib.call("ge_event_elapsed_ms", self.handles[i], self.handles[j], C.byref(ms))
+        return float(ms.value)
+
+    def close(self):
+        for h in self.handles:
+            _lib.load().ge_event_destroy(h)
+        self.handles = []

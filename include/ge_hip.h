@@ -1,0 +1,147 @@
+/* ge_hip.h -- flat C ABI of libge_hip.so, the MI355X (gfx950) drop-in for the hot path of
+ * greysun/GraphEmbeddings' holE.py (gather -> max-norm clip -> ComplEx / HolE score -> sigmoid ->
+ * pairwise hinge -> gradient of the SUM -> sparse SGD scatter), plus the type-safe corruption
+ * sampler and the 1-vs-K candidate scorer.
+ *
+ * The holE.py path has no FFI of its own (it is in-process TensorFlow); the calling convention
+ * below is the one the reference uses for its only native library, init.so
+ * (init.cpp:47-48,129-142,223-224 loaded by transE.py:9-10, buffers passed as raw addresses
+ * transE.py:95-112): C linkage, caller-owned caller-sized flat buffers, int32 ids.  Differences
+ * that make it usable from a GPU training loop: every entry point returns an int status
+ * (0 = ok, <0 = -errno style argument error, >0 = hipError_t), takes the hipStream_t it must
+ * enqueue on (as void*), never synchronises, never allocates, and keeps no global state.
+ *
+ * All pointers except where noted are DEVICE pointers (e.g. torch.Tensor.data_ptr()).
+ * `table` is the single shared entity+relation table of holE.py:263-264: row-major fp32 [N, d],
+ * first d/2 floats of a row = real parts, last d/2 = imaginary parts (holE.py:164-166).
+ * Triples are int32 [B,3] in the reference's column order (head, tail, relation)
+ * (holE.py:76-81, 181-185).  A triple with an id outside [0,N) yields NaN / is skipped.
+ */
+#ifndef GE_HIP_H
+#define GE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GE_VERSION 100 /* 0.1.0 */
+
+/* argument errors (negative, -errno style) */
+#define GE_EINVAL (-22)  /* bad dimension / null pointer / misaligned buffer */
+#define GE_ENOTSUP (-95) /* dimension outside the compiled kernel range */
+#define GE_ENOMEM (-12)  /* workspace too small */
+
+/* ge_corrupt_batch modes */
+#define GE_CORRUPT_BATCH_COIN 0 /* reference: one heads/tails coin per batch (holE.py:137-140) */
+#define GE_CORRUPT_ROW_COIN 1   /* one coin per row (extension) */
+#define GE_CORRUPT_HEADS 2      /* holE.py:97-114 */
+#define GE_CORRUPT_TAILS 3      /* holE.py:117-133 */
+
+int ge_version(void);
+
+/* Largest embedding_dim the compiled kernels accept (score path / train path). */
+int ge_max_dim(void);
+
+/* --- evaluate_triples (holE.py:179-202), ComplEx: out[i] = sigma(sum_k Re(h_k r_k conj(t_k)))
+ * with rows clipped to max_norm as tf.nn.embedding_lookup(max_norm=1) does (holE.py:162).
+ * apply_sigmoid=0 returns the raw score.  d must be even.  out: [B] fp32. */
+int ge_complex_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                     float max_norm, int apply_sigmoid, float* out, void* stream);
+
+/* --- HolE score of README.md:42: sigma(sum_k r_k [h (star) t]_k), circular correlation over the
+ * full d real values of the clipped rows.  Same layout as ge_complex_score. */
+int ge_hole_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                  float max_norm, int apply_sigmoid, float* out, void* stream);
+
+/* --- evaluate_batch forward only (holE.py:222-234): loss[i] = max(E(pos_i) - E(neg_i) + margin, 0).
+ * model: 0 = ComplEx, 1 = HolE.  sig_out (nullable) receives E(pos) in [0,B) and E(neg) in [B,2B). */
+int ge_hinge_loss(const float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                  int64_t B, float margin, float max_norm, int model, float* loss, float* sig_out,
+                  void* stream);
+
+/* --- one SGD step of holE.py:296 on the hinge of holE.py:231: forward of both sides, gradient of
+ * SUM_i loss_i through sigmoid, score and the clip, then table[row] -= lr * grad for every
+ * occurrence (ScatterSub semantics, duplicates accumulate; holE-20170724/graph.pbtxt:47850-48001).
+ * Every gradient is evaluated against the table as it was before the call.  In place on `table`.
+ * workspace: device scratch of at least ge_hinge_step_workspace_bytes(B, d) bytes, 256-B aligned.
+ * loss: [B] fp32.  Rows that pos and neg share (relation, and the uncorrupted entity) are read
+ * and updated once with the summed gradient. */
+size_t ge_hinge_step_workspace_bytes(int64_t B, int32_t d);
+int ge_complex_hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                          int64_t B, float margin, float lr, float max_norm, float* loss,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int ge_hole_hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                       int64_t B, float margin, float lr, float max_norm, float* loss,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* --- the two halves of the step, exposed for the row-sharded multi-GPU path (rows are fetched
+ * from / gradients routed to their owner GPU between the halves).
+ * ge_hinge_grad: `rows` is any [N,d] row store (the table itself, or a staging buffer of fetched
+ * rows with pos/neg re-indexed into it).  Emits IndexedSlices: grad_idx [6B] int32 (row index in
+ * `rows`, or -1 for an empty slot) and grad_val [6B,d] fp32 already multiplied by -lr, slot order
+ * per pair: h+, t+, r+, h-, t-, r-.  model: 0 = ComplEx, 1 = HolE.
+ * ge_scatter_add_rows: table[idx[i]] += val[i] for idx[i] >= 0, float atomics.
+ * ge_gather_rows: out[i] = table[idx[i]] (zeros for idx[i] < 0). */
+int ge_hinge_grad(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
+                  int64_t B, float margin, float lr, float max_norm, int model, float* loss,
+                  int32_t* grad_idx, float* grad_val, void* stream);
+int ge_scatter_add_rows(float* table, int64_t N, int32_t d, const int32_t* idx, const float* val,
+                        int64_t R, void* stream);
+int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx, int64_t R,
+                   float* out, void* stream);
+
+/* --- corrupt_batch (holE.py:152-153 -> 136-140 -> 97-133) fused with the per-batch host
+ * resample of holE.py:343-347.  id_to_type [N] int32 type code per table row (-1 = unknown, the
+ * reference's '?' default -> corrupted id -1, holE.py:39); type lists as CSR type_offsets
+ * [n_types+1] int64 / type_ids int32.  Row i's replaced entity is drawn as the reference does:
+ * uniform slot in [0,padded_size) of a per-batch with-replacement subsample of its type's list
+ * (padded_size = 0: uniform over the whole list).  Randomness is a counter-based Philox4x32-10
+ * stream keyed by (seed, step, row/type) -- no state, bitwise reproducible (oracle/hole_oracle.py
+ * states the stream).  neg: [B,3] int32. */
+int ge_corrupt_batch(const int32_t* pos, int64_t B, const int32_t* id_to_type, int64_t N,
+                     const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,
+                     uint64_t seed, uint64_t step, int32_t padded_size, int32_t mode, int32_t* neg,
+                     void* stream);
+
+/* --- 1-vs-K candidate scoring (the inference loop of holE.py:564-569: fixed (head, relation)
+ * against many tails; also K shared negatives per positive).  hr: [B,2] int32 (fixed entity,
+ * relation); cand: [K] int32 candidate entity rows; cand_is_head = 0 scores (fixed, cand_j, rel),
+ * 1 scores (cand_j, fixed, rel).  out: [B,K] fp32 row-major.  Runs as an fp32-MFMA GEMM
+ * S = Q . T^T with Q = clip(fixed) o clip(rel) (complex product) and T the clipped candidates. */
+int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
+                         const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
+                         int cand_is_head, float* out, void* stream);
+
+/* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
+ * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already
+ * shuffled [T,3] int32 array, wrapping to row 0 when the next batch would run past T -- the
+ * reference's shuffle queue never yields a short batch, holE.py:283); negatives from
+ * ge_corrupt_batch with step = global_step0 + s; lr_s = lr0 / (1 + decay_rate * (global_step0+s) /
+ * decay_steps) (tf.train.inverse_time_decay, holE.py:292-294; decay_steps <= 0 keeps lr0); then one
+ * ge_*_hinge_step.  No host synchronisation; every launch goes to `stream` in order.
+ * neg_ws: device [B,3] int32 scratch.  loss: device [n_steps*B] when keep_all_losses, else [B]
+ * (last step).  model: 0 ComplEx, 1 HolE.
+ * ev_pairs (nullable, HOST array of 2*n_steps events from ge_event_create): events are recorded on
+ * `stream` immediately before and after kernel `ev_kernel` of every step (0 = sampler,
+ * 1 = gather+score+hinge+grad, 2 = scatter-add) -- the hook bench.py uses to time one kernel. */
+int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T,
+                   int64_t first_row, int64_t B, int64_t n_steps, const int32_t* id_to_type,
+                   const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,
+                   uint64_t seed, uint64_t global_step0, int32_t padded_size, int32_t mode,
+                   float margin, float lr0, float decay_steps, float decay_rate, float max_norm,
+                   int model, float* loss, int keep_all_losses, int32_t* neg_ws, void* workspace,
+                   size_t workspace_bytes, void** ev_pairs, int ev_kernel, void* stream);
+
+/* --- thin wrappers over hipEvent_t so a ctypes host can time kernels on the launch stream. */
+int ge_event_create(void** ev);
+int ge_event_destroy(void* ev);
+int ge_event_record(void* ev, void* stream);
+int ge_event_synchronize(void* ev);
+int ge_event_elapsed_ms(void* start, void* stop, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GE_HIP_H */

@@ -1,0 +1,300 @@
+"""Parity of the HIP path (through the C ABI, via the Python host) against the CPU oracle.
+
+Bars: integer / index work (sampler, gather, IndexedSlices indices) bit-exact; floating point within
+the tolerance BASELINE.json's north_star states -- scores within 1e-5 of the fp32 reference
+arithmetic (we hold sigma and raw scores to 1e-5 absolute against the fp64 restatement), and the
+table after one step within 5e-6 absolute (fp32 atomics change the summation order).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import hole_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-5   # north_star: "scores matching the reference within 1e-5 fp32"
+TABLE_TOL = 5e-6
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU: the HIP path cannot be checked")
+    from graphembeddings_amd import hole
+    return hole
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "golden_v1.npz"))
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+# ---------------------------------------------------------------- evaluate_triples
+@pytest.mark.parametrize("d", [50, 128, 200])
+def test_score_matches_golden(H, G, d):
+    table, pos = dev(G[f"d{d}_table"]), dev(G[f"d{d}_pos"])
+    sig = H.evaluate_triples(pos, table).cpu().numpy()
+    assert sig.shape == (len(G[f"d{d}_pos"]), 1)
+    assert np.abs(sig[:, 0] - G[f"d{d}_sigma"]).max() < SCORE_TOL
+    raw = H.evaluate_triples(pos, table, apply_sigmoid=False).cpu().numpy()[:, 0]
+    assert np.abs(raw - G[f"d{d}_score_raw"]).max() < SCORE_TOL
+    hole_raw = H.evaluate_triples(pos, table, model="hole", apply_sigmoid=False).cpu().numpy()[:, 0]
+    assert np.abs(hole_raw - G[f"d{d}_hole_raw"]).max() < SCORE_TOL
+    # int64 triples are accepted (inference placeholder, holE.py:547)
+    sig64 = H.evaluate_triples(pos.to(torch.int64), table).cpu().numpy()
+    assert np.array_equal(sig, sig64)
+
+
+@pytest.mark.parametrize("B", [0, 1, 3, 65, 1000])
+def test_score_ragged_batch_sizes(H, G, B):
+    table = G["d200_table"]
+    rng = np.random.default_rng(B)
+    tr = rng.integers(0, table.shape[0], size=(B, 3)).astype(np.int32)
+    got = H.evaluate_triples(dev(tr), dev(table)).cpu().numpy()
+    assert got.shape == (B, 1)
+    if B:
+        assert np.abs(got[:, 0] - O.evaluate_triples(tr, table.astype(np.float64))[:, 0]).max() < SCORE_TOL
+
+
+@pytest.mark.parametrize("d", [2, 8, 30, 64, 100, 256, 400, 512, 1024])
+def test_score_other_dims(H, d):
+    rng = np.random.default_rng(d)
+    table = (rng.standard_normal((40, d)) * rng.uniform(0.1, 1.5, (40, 1)) / np.sqrt(d)).astype(np.float32)
+    tr = rng.integers(0, 40, size=(77, 3)).astype(np.int32)
+    got = H.evaluate_triples(dev(tr), dev(table)).cpu().numpy()[:, 0]
+    assert np.abs(got - O.evaluate_triples(tr, table.astype(np.float64))[:, 0]).max() < SCORE_TOL
+    if d <= 512:
+        goth = H.evaluate_triples(dev(tr), dev(table), model="hole").cpu().numpy()[:, 0]
+        assert np.abs(goth - O.hole_evaluate_triples(tr, table.astype(np.float64))[:, 0]).max() < SCORE_TOL
+
+
+def test_unsupported_dims_fail_loudly(H):
+    from graphembeddings_amd._lib import GeError
+    table = torch.zeros(4, 4096, device="cuda")
+    tr = torch.zeros(2, 3, dtype=torch.int32, device="cuda")
+    with pytest.raises(GeError):
+        H.evaluate_triples(tr, table)
+    with pytest.raises(GeError):
+        H.evaluate_triples(tr, torch.zeros(4, 7, device="cuda"))  # odd d has no complex split
+
+
+def test_bad_ids_give_nan_and_touch_nothing(H, G):
+    table = dev(G["d50_table"])
+    tr = dev(np.array([[1, 2, 3], [1, 2, 64], [-1, 2, 3]], dtype=np.int32))
+    s = H.evaluate_triples(tr, table).cpu().numpy()[:, 0]
+    assert np.isfinite(s[0]) and np.isnan(s[1]) and np.isnan(s[2])
+    before = table.clone()
+    opt = H.HingeSGD(table, 3, margin=0.2)
+    loss = opt.step(tr, tr.clone(), 0.1).cpu().numpy()[:, 0]
+    assert np.isnan(loss[1]) and np.isnan(loss[2]) and np.isfinite(loss[0])
+    torch.cuda.synchronize()
+    # pair 0 has pos == neg: gradients cancel exactly; pairs 1,2 are skipped
+    assert np.abs((table - before).cpu().numpy()).max() < 1e-7
+
+
+# ---------------------------------------------------------------- hinge forward
+@pytest.mark.parametrize("model", ["complex", "hole"])
+@pytest.mark.parametrize("d", [50, 128, 200])
+def test_hinge_loss_forward(H, G, d, model):
+    table, pos, neg = dev(G[f"d{d}_table"]), dev(G[f"d{d}_pos"]), dev(G[f"d{d}_neg"])
+    tag = "" if model == "complex" else "_hole"
+    for margin in (0.2, 0.0, -0.5):
+        loss, sp, sn = H.hinge_loss(pos, neg, table, margin=margin, model=model, return_sigmoids=True)
+        assert np.abs(loss.cpu().numpy()[:, 0] - G[f"d{d}_m{margin}{tag}_loss"]).max() < SCORE_TOL
+    if model == "complex":
+        assert np.abs(sp.cpu().numpy()[:, 0] - G[f"d{d}_sigma"]).max() < SCORE_TOL
+
+
+# ---------------------------------------------------------------- one SGD step
+@pytest.mark.parametrize("model", ["complex", "hole"])
+@pytest.mark.parametrize("d", [50, 128, 200])
+@pytest.mark.parametrize("margin", [0.2, 0.0])
+def test_hinge_step_matches_golden(H, G, d, model, margin):
+    tag = "" if model == "complex" else "_hole"
+    table = dev(G[f"d{d}_table"]).clone()
+    pos, neg = dev(G[f"d{d}_pos"]), dev(G[f"d{d}_neg"])
+    opt = H.HingeSGD(table, len(G[f"d{d}_pos"]), margin=margin, model=model)
+    loss = opt.step(pos, neg, 0.05).cpu().numpy()[:, 0]
+    exp_loss = G[f"d{d}_m{margin}{tag}_loss"]
+    assert np.abs(loss - exp_loss).max() < SCORE_TOL
+    got = table.cpu().numpy()
+    exp = G[f"d{d}_m{margin}{tag}_table_after"]
+    # a pair whose fp64 pre-activation is within fp32 rounding of the kink may flip its mask: the
+    # rows it touches are excluded (none for margin 0.2)
+    pre64 = _pre_activation(G, d, model, margin)
+    risky = np.abs(pre64) < 1e-6
+    if risky.any():
+        rows = np.unique(np.concatenate([G[f"d{d}_pos"][risky].ravel(), G[f"d{d}_neg"][risky].ravel()]))
+        mask = np.ones(got.shape[0], bool); mask[rows] = False
+        got, exp = got[mask], exp[mask]
+        assert margin == 0.0
+    assert np.abs(got - exp).max() < TABLE_TOL
+
+
+def _pre_activation(G, d, model, margin):
+    t64 = G[f"d{d}_table"].astype(np.float64)
+    f = O.complex_score if model == "complex" else O.hole_score
+    return O.sigmoid(f(G[f"d{d}_pos"], t64)) - O.sigmoid(f(G[f"d{d}_neg"], t64)) + margin
+
+
+@pytest.mark.parametrize("model", ["complex", "hole"])
+def test_indexed_slices_match_closed_form(H, G, model):
+    d = 200
+    table64 = G[f"d{d}_table"].astype(np.float64)
+    pos, neg = G[f"d{d}_pos"], G[f"d{d}_neg"]
+    loss, gi, gv = H.hinge_grad(dev(G[f"d{d}_table"]), dev(pos), dev(neg), 0.05, margin=0.2, model=model)
+    gi, gv = gi.cpu().numpy(), gv.cpu().numpy()
+    B = len(pos)
+    assert gi.shape == (6 * B,) and gv.shape == (6 * B, d)
+    # slot order h+,t+,r+,h-,t-,r-; shared rows merged into the positive slot, the other slot is -1
+    gi2 = gi.reshape(B, 6)
+    for X in range(3):
+        same = pos[:, X] == neg[:, X]
+        assert np.array_equal(gi2[:, X], pos[:, X])
+        assert np.array_equal(gi2[:, 3 + X], np.where(same, -1, neg[:, X]))
+    acc = np.zeros_like(table64)
+    live = gi >= 0
+    np.add.at(acc, gi[live], gv[live].astype(np.float64))
+    idx, val, _ = O.hinge_grads(pos, neg, table64, margin=0.2, model=model)
+    exp = np.zeros_like(table64)
+    np.add.at(exp, idx, -0.05 * val)
+    assert np.abs(acc - exp).max() < TABLE_TOL
+
+
+def test_all_inactive_margin_leaves_table_bit_identical(H, G):
+    table = dev(G["d200_table"]).clone()
+    before = table.clone()
+    opt = H.HingeSGD(table, 64, margin=-0.5)
+    loss = opt.step(dev(G["d200_pos"]), dev(G["d200_neg"]), 0.05)
+    torch.cuda.synchronize()
+    assert (loss == 0).all() and torch.equal(table, before)
+
+
+# ---------------------------------------------------------------- config-2 size against the C port
+@pytest.mark.parametrize("model,d,B", [("complex", 200, 4096), ("complex", 50, 128), ("hole", 200, 1024)])
+def test_step_at_baseline_sizes_against_c_port(H, model, d, B):
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    rng = np.random.default_rng(7)
+    table = O.init_table(fb.entity_count, d, seed=3)
+    # scale a third of the rows past the unit ball so the clip and its Jacobian are exercised
+    big = rng.random(fb.entity_count) < 0.33
+    table[big] *= (rng.uniform(1.1, 2.0, big.sum()) / np.linalg.norm(table[big], axis=1))[:, None]
+    pos = D.synthetic_fb15k_triples(fb, n_triples=B, seed=5)
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    neg_t = H.corrupt_batch(tt, fb.relation_count, dev(pos), seed=9, step=4)
+    neg = neg_t.cpu().numpy()
+    assert np.array_equal(neg, CO.corrupt_batch(pos, id_to_type, offsets, ids, 9, 4, 1024, 0))  # bit-exact
+    gtab = dev(table).clone()
+    opt = H.HingeSGD(gtab, B, margin=0.2, model=model)
+    loss = opt.step(dev(pos), neg_t, 0.1).cpu().numpy()[:, 0]
+    ctab = table.copy()
+    closs = CO.hinge_step(ctab, pos, neg, 0.2, 0.1, hole=(model == "hole"), threads=8)
+    assert np.abs(loss - closs).max() < SCORE_TOL
+    assert np.abs(gtab.cpu().numpy() - ctab).max() < 2e-5   # two fp32 implementations, 100s of adds on hot rows
+    # scores of the updated table agree too
+    s = H.evaluate_triples(dev(pos), gtab, model=model).cpu().numpy()[:, 0]
+    assert np.abs(s - CO.complex_score(ctab, pos, hole=(model == "hole"), threads=8)).max() < SCORE_TOL
+
+
+def test_step_is_linear_in_duplicated_pairs(H, G):
+    # ScatterSub applies every occurrence: a batch holding each pair twice moves the table twice as far
+    t0 = dev(G["d200_table"])
+    pos, neg = dev(G["d200_pos"]), dev(G["d200_neg"])
+    a = t0.clone(); H.HingeSGD(a, 64).step(pos, neg, 0.01)
+    b = t0.clone(); H.HingeSGD(b, 128).step(torch.cat([pos, pos]), torch.cat([neg, neg]), 0.01)
+    torch.cuda.synchronize()
+    assert torch.allclose((b - t0), 2 * (a - t0), atol=2e-6, rtol=0)
+
+
+def test_scores_are_permutation_equivariant_at_full_size(H):
+    N, d, B = 16296, 200, 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(0)
+    table = (torch.randn(N, d, generator=g) * 0.1).cuda()
+    tr = torch.randint(0, N, (B, 3), generator=g, dtype=torch.int32).cuda()
+    s = H.evaluate_triples(tr, table)
+    perm = torch.randperm(B, generator=g).cuda()
+    s2 = H.evaluate_triples(tr[perm].contiguous(), table)
+    assert torch.equal(s[perm], s2)   # bitwise: each triple is reduced in a fixed lane order
+    assert torch.isfinite(s).all() and float(s.min()) > 0 and float(s.max()) < 1
+
+
+# ---------------------------------------------------------------- sampler
+def test_corrupt_batch_bit_exact(H, G):
+    tt = None
+    pos = dev(G["smp_pos"])
+    for (seed, step, padded) in ((0, 0, 1024), (0x1234567890ABCDEF, 77, 16), (5, 2**40 + 3, 0)):
+        tt = H.TypeTables.from_host(G["smp_id_to_type"], G["smp_offsets"], G["smp_ids"], padded_size=padded)
+        for mode in range(4):
+            neg = H.corrupt_batch(tt, 8, pos, seed=seed, step=step, mode=mode).cpu().numpy()
+            assert np.array_equal(neg, G[f"smp_neg_m{mode}_s{seed}_t{step}_p{padded}"])
+    # evaluate_batch = corrupt + hinge, deterministic in (seed, step)
+    table = dev(np.random.default_rng(0).standard_normal((len(G["smp_id_to_type"]), 64)).astype(np.float32) * 0.1)
+    l1 = H.evaluate_batch(pos, table, tt, None, 8, seed=1, step=2)
+    l2 = H.evaluate_batch(pos, table, tt, None, 8, seed=1, step=2)
+    assert l1.shape == (len(G["smp_pos"]), 1) and torch.equal(l1, l2)
+
+
+# ---------------------------------------------------------------- rows
+def test_gather_and_scatter_rows(H):
+    rng = np.random.default_rng(1)
+    for d in (200, 50, 7):
+        table = rng.standard_normal((100, d)).astype(np.float32)
+        idx = rng.integers(-1, 100, size=333).astype(np.int32)
+        idx[:5] = [3, 3, 3, -1, 99]
+        got = H.gather_rows(dev(table), dev(idx)).cpu().numpy()
+        exp = np.where((idx >= 0)[:, None], table[np.clip(idx, 0, 99)], 0.0)
+        assert np.array_equal(got, exp)
+        val = rng.standard_normal((333, d)).astype(np.float32)
+        t = dev(table).clone()
+        H.scatter_add_rows(t, dev(idx), dev(val))
+        exp = table.astype(np.float64)
+        np.add.at(exp, idx[idx >= 0], val[idx >= 0].astype(np.float64))
+        assert np.abs(t.cpu().numpy() - exp).max() < 1e-5
+
+
+# ---------------------------------------------------------------- 1-vs-K (MFMA GEMM)
+@pytest.mark.parametrize("d,B,K", [(200, 37, 129), (200, 256, 256), (50, 5, 70), (128, 130, 64)])
+@pytest.mark.parametrize("cand_is_head", [False, True])
+def test_score_candidates_matches_per_triple_scores(H, d, B, K, cand_is_head):
+    rng = np.random.default_rng(d + B)
+    N = 300
+    table = (rng.standard_normal((N, d)) * rng.uniform(0.3, 2.0, (N, 1)) / np.sqrt(d)).astype(np.float32)
+    hr = np.stack([rng.integers(10, N, B), rng.integers(0, 10, B)], axis=1).astype(np.int32)
+    cand = rng.permutation(np.arange(10, N))[:K].astype(np.int32)
+    got = H.score_candidates(dev(table), dev(hr), dev(cand), cand_is_head=cand_is_head).cpu().numpy()
+    assert got.shape == (B, K)
+    fixed = np.repeat(hr[:, 0], K); rel = np.repeat(hr[:, 1], K); c = np.tile(cand, B)
+    tr = np.stack([c, fixed, rel], 1) if cand_is_head else np.stack([fixed, c, rel], 1)
+    exp = O.evaluate_triples(tr, table.astype(np.float64))[:, 0].reshape(B, K)
+    assert np.abs(got - exp).max() < SCORE_TOL
+    # and it equals the per-triple kernel
+    per = H.evaluate_triples(dev(tr.astype(np.int32)), dev(table)).cpu().numpy().reshape(B, K)
+    assert np.abs(got - per).max() < SCORE_TOL
+
+
+def test_score_candidates_full_fb15k_shape(H):
+    # config 5 shape: B=4096 positives x 256 shared negatives, d=200
+    N, d, B, K = 16296, 200, 4096, 256
+    g = torch.Generator(device="cpu").manual_seed(1)
+    table = (torch.randn(N, d, generator=g) * 0.12).cuda()
+    hr = torch.stack([torch.randint(1345, N, (B,), generator=g), torch.randint(0, 1345, (B,), generator=g)], 1).int().cuda()
+    cand = torch.randint(1345, N, (K,), generator=g).int().cuda()
+    out = H.score_candidates(table, hr, cand)
+    rows = torch.randint(0, B, (2000,), generator=g)
+    cols = torch.randint(0, K, (2000,), generator=g)
+    tr = torch.stack([hr[rows.cuda(), 0], cand[cols.cuda()], hr[rows.cuda(), 1]], 1).contiguous()
+    per = H.evaluate_triples(tr, table)[:, 0]
+    assert (out[rows.cuda(), cols.cuda()] - per).abs().max().item() < SCORE_TOL
