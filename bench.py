@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--model", default="complex", choices=["complex", "hole"])
+    ap.add_argument("--sharded", action="store_true", help="run the row-sharded (all-to-all) path even on 1 GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--entities", type=int, default=1_200_000)
@@ -167,7 +168,7 @@ def run_single(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.sharded:
         from graphembeddings_amd import sharded_bench
         sharded_bench.run(args)
         return

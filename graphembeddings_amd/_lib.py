@@ -62,6 +62,11 @@ def load():
     """Load libge_hip.so; raise loudly when it is absent (no fallback path exists)."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and must be
+        # loaded FIRST so that this library binds to the same runtime instance (same soname); the
+        # stream handles and device pointers we are handed belong to it.  Loaded the other way round
+        # the process ends up with two runtimes and the second one finds no device.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found. Build it with `python -m graphembeddings_amd.build` "

@@ -158,11 +158,14 @@ def test_indexed_slices_match_closed_form(H, G, model):
     B = len(pos)
     assert gi.shape == (6 * B,) and gv.shape == (6 * B, d)
     # slot order h+,t+,r+,h-,t-,r-; shared rows merged into the positive slot, the other slot is -1
+    # pairs whose hinge is inactive (MaximumGrad mask 0) emit no slices at all
     gi2 = gi.reshape(B, 6)
+    on = _pre_activation(G, d, model, 0.2) >= 0
+    assert on.any() and (model == "hole" or not on.all())
     for X in range(3):
         same = pos[:, X] == neg[:, X]
-        assert np.array_equal(gi2[:, X], pos[:, X])
-        assert np.array_equal(gi2[:, 3 + X], np.where(same, -1, neg[:, X]))
+        assert np.array_equal(gi2[:, X], np.where(on, pos[:, X], -1))
+        assert np.array_equal(gi2[:, 3 + X], np.where(on & ~same, neg[:, X], -1))
     acc = np.zeros_like(table64)
     live = gi >= 0
     np.add.at(acc, gi[live], gv[live].astype(np.float64))
@@ -298,3 +301,26 @@ def test_score_candidates_full_fb15k_shape(H):
     tr = torch.stack([hr[rows.cuda(), 0], cand[cols.cuda()], hr[rows.cuda(), 1]], 1).contiguous()
     per = H.evaluate_triples(tr, table)[:, 0]
     assert (out[rows.cuda(), cols.cuda()] - per).abs().max().item() < SCORE_TOL
+
+
+# ---------------------------------------------------------------- row-sharded path, HIP kernels
+def test_sharded_trainer_single_rank_uses_hip_kernels(H):
+    """world_size 1 on the GPU: the exchange degenerates to local copies, the four kernels are the
+    real HIP ones.  Result must equal the plain fused step (same negatives)."""
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import sharded as S
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    table = dev(O.init_table(fb.entity_count, 200, seed=2) * 6.0)
+    pos = dev(D.synthetic_fb15k_triples(fb, n_triples=2048, seed=3))
+    a = table.clone()
+    tr = S.ShardedTrainer(a, fb.entity_count, tt, seed=4)
+    loss_s = tr.step(pos, lr=0.1)
+    neg = H.corrupt_batch(tt, fb.relation_count, pos, seed=4, step=0)
+    b = table.clone()
+    loss_p = H.HingeSGD(b, 2048).step(pos, neg, 0.1)[:, 0]
+    torch.cuda.synchronize()
+    assert (loss_s - loss_p).abs().max().item() < SCORE_TOL
+    assert (a - b).abs().max().item() < TABLE_TOL
+    assert tr.stats.unique_rows > 0 and tr.stats.remote_rows == 0

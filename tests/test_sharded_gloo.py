@@ -1,0 +1,140 @@
+"""Row-sharded multi-GPU step, exercised with world_size-2 gloo processes on CPU.
+
+The exchange logic (dedup, bucket by owner, all_to_all of ids / rows / gradient sums, apply at the
+owner) is the product code of graphembeddings_amd/sharded.py; the four kernels it calls are replaced
+here by an oracle-backed double (tests may use the oracle; the product default is the HIP path and
+raises without a GPU).  Correctness oracle = the single-process result on the same global batch.
+"""
+import os
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import hole_oracle as O
+
+
+class OracleKernels:
+    """NumPy stand-ins with the same contracts as HipKernels (graphembeddings_amd/sharded.py)."""
+
+    def corrupt_batch(self, tt, pos, seed, step, mode):
+        neg = O.corrupt_batch(pos.numpy(), tt.id_to_type, tt.type_offsets, tt.type_ids, seed, step,
+                              tt.padded_size, mode)
+        return torch.as_tensor(neg)
+
+    def gather_rows(self, table, idx):
+        i = idx.numpy().astype(np.int64)
+        out = np.where((i >= 0)[:, None], table.numpy()[np.clip(i, 0, None)], 0.0)
+        return torch.as_tensor(out.astype(table.numpy().dtype))
+
+    def hinge_grad(self, rows, pos, neg, lr, margin, model, max_norm):
+        r = rows.numpy().astype(np.float64)
+        idx, val, loss = O.hinge_grads(pos.numpy(), neg.numpy(), r, margin, max_norm, model)
+        return (torch.as_tensor(loss.astype(np.float32)), torch.as_tensor(idx.astype(np.int32)),
+                torch.as_tensor((-lr * val).astype(rows.numpy().dtype)))
+
+    def scatter_add_rows(self, table, idx, val):
+        i = idx.numpy().astype(np.int64)
+        t = table.numpy()
+        np.add.at(t, i[i >= 0], val.numpy()[i >= 0])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(dtype=np.float64):
+    rng = np.random.default_rng(5)
+    N, d, R = 301, 16, 7                      # N not divisible by the world size on purpose
+    table = rng.standard_normal((N, d)) * rng.uniform(0.1, 0.6, (N, 1))
+    n_types = 4
+    type_of = rng.integers(0, n_types, N - R)
+    ids_by_type = [np.arange(R, N)[type_of == t] for t in range(n_types)]
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in ids_by_type])]).astype(np.int64)
+    type_ids = np.concatenate(ids_by_type).astype(np.int32)
+    id_to_type = np.concatenate([np.full(R, -1), type_of]).astype(np.int32)
+    B = 64
+    pos = np.stack([rng.integers(R, N, B), rng.integers(R, N, B), rng.integers(0, R, B)], 1).astype(np.int32)
+    pos[:8, 0] = R + 1                        # a hot head shared by both ranks' halves
+    pos[B // 2:B // 2 + 8, 0] = R + 1
+    return table.astype(dtype), id_to_type, offsets, type_ids, pos
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphembeddings_amd import sharded as S
+        table, id_to_type, offsets, type_ids, pos = _problem()
+        tt = SimpleNamespace(id_to_type=id_to_type, type_offsets=offsets, type_ids=type_ids, padded_size=32)
+        full = torch.as_tensor(table)
+        tr = S.ShardedTrainer(S.shard_rows(full, rank, world), full.shape[0], tt, margin=0.2, seed=9,
+                              kernels=OracleKernels())
+        B = len(pos)
+        mine = torch.as_tensor(pos[rank * B // world:(rank + 1) * B // world])
+        losses = []
+        for step in range(3):                 # several steps: updates must be visible to later fetches
+            losses.append(tr.step(mine, lr=0.05))
+        out = tr.gather_full_table()
+        mean = tr.mean_loss(losses[-1])
+        if rank == 0:
+            q.put((out.numpy(), [l.numpy() for l in losses], mean, tr.stats.unique_rows))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_equals_single_process_result(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got_table, got_losses, mean, uniq = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference on the same global batches, same sampler streams
+    table, id_to_type, offsets, type_ids, pos = _problem()
+    B = len(pos)
+    ref = table.copy()
+    for step in range(3):
+        negs = [O.corrupt_batch(pos[r * B // world:(r + 1) * B // world], id_to_type, offsets, type_ids, 9,
+                                step * world + r, 32, 0) for r in range(world)]
+        neg = np.concatenate(negs, 0)
+        ref, loss = O.sgd_step(ref, pos, neg, lr=0.05, margin=0.2)
+        assert np.abs(got_losses[step] - loss[:B // world]).max() < 1e-6   # rank 0 holds the first slice
+    assert np.abs(got_table - ref).max() < 1e-12
+    assert uniq > 0 and np.isfinite(mean)
+
+
+def test_single_rank_degenerates_to_plain_step():
+    from graphembeddings_amd import sharded as S
+    table, id_to_type, offsets, type_ids, pos = _problem()
+    tt = SimpleNamespace(id_to_type=id_to_type, type_offsets=offsets, type_ids=type_ids, padded_size=32)
+    tr = S.ShardedTrainer(torch.as_tensor(table.copy()), table.shape[0], tt, seed=1, kernels=OracleKernels())
+    neg = O.corrupt_batch(pos, id_to_type, offsets, type_ids, 1, 0, 32, 0)
+    loss = tr.step(torch.as_tensor(pos), lr=0.1)
+    ref, rloss = O.sgd_step(table, pos, neg, lr=0.1, margin=0.2)
+    assert np.abs(tr.shard.numpy() - ref).max() < 1e-12
+    assert np.abs(loss.numpy() - rloss).max() < 1e-6
+
+
+def test_product_default_kernels_need_the_gpu():
+    from graphembeddings_amd import sharded as S
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    table, id_to_type, offsets, type_ids, pos = _problem(np.float32)
+    tt = SimpleNamespace(id_to_type=id_to_type, type_offsets=offsets, type_ids=type_ids, padded_size=32)
+    tr = S.ShardedTrainer(torch.as_tensor(table), table.shape[0], tt)
+    with pytest.raises(RuntimeError):
+        tr.step(torch.as_tensor(pos), lr=0.1)
