@@ -247,7 +247,8 @@ def test_corrupt_batch_bit_exact(H, G):
     table = dev(np.random.default_rng(0).standard_normal((len(G["smp_id_to_type"]), 64)).astype(np.float32) * 0.1)
     l1 = H.evaluate_batch(pos, table, tt, None, 8, seed=1, step=2)
     l2 = H.evaluate_batch(pos, table, tt, None, 8, seed=1, step=2)
-    assert l1.shape == (len(G["smp_pos"]), 1) and torch.equal(l1, l2)
+    assert l1.shape == (len(G["smp_pos"]), 1) and torch.allclose(l1, l2, rtol=0, atol=0, equal_nan=True)
+    assert torch.isnan(l1).sum().item() == 2   # the two rows whose corrupted id is unknown (-1)
 
 
 # ---------------------------------------------------------------- rows
