@@ -16,6 +16,9 @@ int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const floa
 int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float*, hipStream_t);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
+size_t hinge_ws_bytes(int64_t, int32_t);
+size_t train_ws_bytes(int64_t, int32_t);
+int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, hipStream_t);
 }  // namespace ge
 
 using namespace ge;
@@ -81,7 +84,12 @@ int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx,
 // workspace layout: [grad_idx: 6B int32, padded to 256 B][grad_val: 6B*d fp32]
 size_t ge_hinge_step_workspace_bytes(int64_t B, int32_t d) {
   if (B <= 0 || d <= 0) return 0;
-  return align_up(sizeof(int32_t) * 6 * (size_t)B, 256) + sizeof(float) * 6 * (size_t)B * (size_t)d;
+  return hinge_ws_bytes(B, d);
+}
+
+size_t ge_train_workspace_bytes(int64_t B, int32_t d) {
+  if (B <= 0 || d <= 0) return 0;
+  return train_ws_bytes(B, d);
 }
 
 static int hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg, int64_t B,
@@ -143,36 +151,11 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
   if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
   if (workspace_bytes < ge_hinge_step_workspace_bytes(B, d)) return GE_ENOMEM;
   if (ev_pairs && (ev_kernel < 0 || ev_kernel > 2)) return GE_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
-  float* gval = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(sizeof(int32_t) * 6 * (size_t)B, 256));
-  int64_t row = first_row % T;
-  for (int64_t s = 0; s < n_steps; ++s) {
-    if (row + B > T) row = 0;  // never a short batch (holE.py:283)
-    const int32_t* pos = triples + 3 * row;
-    const uint64_t gs = global_step0 + (uint64_t)s;
-    const float lr = decay_steps > 0.f ? lr0 / (1.0f + decay_rate * ((float)gs / decay_steps)) : lr0;
-    float* loss_s = keep_all_losses ? loss + s * B : loss;
-    hipEvent_t e0 = ev_pairs ? (hipEvent_t)ev_pairs[2 * s] : nullptr;
-    hipEvent_t e1 = ev_pairs ? (hipEvent_t)ev_pairs[2 * s + 1] : nullptr;
-    int rc;
-    if (e0 && ev_kernel == 0) (void)hipEventRecord(e0, st);
-    rc = corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, gs, padded_size,
-                              mode, neg_ws, st);
-    if (e1 && ev_kernel == 0) (void)hipEventRecord(e1, st);
-    if (rc) return rc;
-    if (e0 && ev_kernel == 1) (void)hipEventRecord(e0, st);
-    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg_ws, B, margin, lr, max_norm, loss_s, gidx, gval, st)
-                    : hole_hinge_grad_launch(table, N, d, pos, neg_ws, B, margin, lr, max_norm, loss_s, gidx, gval, st);
-    if (e1 && ev_kernel == 1) (void)hipEventRecord(e1, st);
-    if (rc) return rc;
-    if (e0 && ev_kernel == 2) (void)hipEventRecord(e0, st);
-    rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st);
-    if (e1 && ev_kernel == 2) (void)hipEventRecord(e1, st);
-    if (rc) return rc;
-    row += B;
-  }
-  return 0;
+  if (mode < 0 || mode > 3 || padded_size < 0 || n_types < 0) return GE_EINVAL;
+  return train_steps_run(table, N, d, triples, T, first_row, B, n_steps, id_to_type, type_offsets, n_types,
+                         type_ids, seed, global_step0, padded_size, mode, margin, lr0, decay_steps, decay_rate,
+                         max_norm, model, loss, keep_all_losses, neg_ws, workspace, workspace_bytes, ev_pairs,
+                         ev_kernel, (hipStream_t)stream);
 }
 
 int ge_event_create(void** ev) {

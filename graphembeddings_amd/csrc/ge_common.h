@@ -90,4 +90,50 @@ __device__ __forceinline__ uint32_t philox_w0(uint32_t c0, uint32_t c1, uint32_t
   return c0;
 }
 
+#define GE_TAG_COIN 0x636F696Eu
+#define GE_TAG_SLOT 0x736C6F74u
+#define GE_TAG_PICK 0x7069636Bu
+#define GE_TAG_SIDE 0x73696465u
+
+// One coin for the whole batch (holE.py:137): heads iff the top bit is 0.
+__device__ __forceinline__ bool batch_coin_heads(uint64_t seed, uint64_t step) {
+  return (philox_w0((uint32_t)step, (uint32_t)(step >> 32), 0u, 0u, (uint32_t)seed ^ GE_TAG_COIN,
+                    (uint32_t)(seed >> 32)) >> 31) == 0;
+}
+
+// Type-safe replacement of one entity (holE.py:104-112 + the host resample of holE.py:343-344):
+// returns the corrupted column in `col` and the replacement id (or -1 for an unknown type).
+__device__ __forceinline__ int32_t corrupt_one(const int32_t (&t)[3], int64_t i, bool batch_heads,
+                                               const int32_t* __restrict__ id_to_type, int64_t N,
+                                               const int64_t* __restrict__ type_offsets, int32_t n_types,
+                                               const int32_t* __restrict__ type_ids, uint64_t seed,
+                                               uint64_t step, int32_t padded_size, int32_t mode, int& col) {
+  const uint32_t slo = (uint32_t)step, shi = (uint32_t)(step >> 32);
+  const uint32_t klo = (uint32_t)seed, khi = (uint32_t)(seed >> 32);
+  const uint32_t ilo = (uint32_t)i, ihi = (uint32_t)((uint64_t)i >> 32);
+  bool heads;
+  if (mode == GE_CORRUPT_BATCH_COIN) heads = batch_heads;
+  else if (mode == GE_CORRUPT_ROW_COIN) heads = (philox_w0(slo, shi, ilo, ihi, klo ^ GE_TAG_SIDE, khi) >> 31) == 0;
+  else heads = (mode == GE_CORRUPT_HEADS);
+  col = heads ? 0 : 1;
+  const int32_t x = t[col];
+  int32_t repl = -1;  // unknown id -> the '?' default row of -1s (holE.py:39)
+  if (x >= 0 && x < N) {
+    const int32_t ty = id_to_type[x];  // id_to_type.lookup (holE.py:104)
+    if (ty >= 0 && ty < n_types) {
+      const int64_t off = type_offsets[ty];
+      const uint64_t len = (uint64_t)(type_offsets[ty + 1] - off);
+      if (len > 0) {
+        uint32_t w = philox_w0(slo, shi, ilo, ihi, klo ^ GE_TAG_SLOT, khi);  // holE.py:108-110
+        if (padded_size > 0) {
+          const uint32_t slot = w % (uint32_t)padded_size;
+          w = philox_w0(slo, shi, (uint32_t)ty, slot, klo ^ GE_TAG_PICK, khi);  // holE.py:343-344
+        }
+        repl = type_ids[off + (int64_t)(((uint64_t)w * len) >> 32)];
+      }
+    }
+  }
+  return repl;
+}
+
 }  // namespace ge

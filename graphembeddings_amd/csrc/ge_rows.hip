@@ -48,46 +48,17 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(
   }
 }
 
-#define TAG_COIN 0x636F696Eu
-#define TAG_SLOT 0x736C6F74u
-#define TAG_PICK 0x7069636Bu
-#define TAG_SIDE 0x73696465u
-
 __global__ __launch_bounds__(kBlock) void corrupt_batch_kernel(
     const int32_t* __restrict__ pos, int64_t B, const int32_t* __restrict__ id_to_type, int64_t N,
     const int64_t* __restrict__ type_offsets, int32_t n_types, const int32_t* __restrict__ type_ids,
     uint64_t seed, uint64_t step, int32_t padded_size, int32_t mode, int32_t* __restrict__ neg) {
-  const uint32_t slo = (uint32_t)step, shi = (uint32_t)(step >> 32);
-  const uint32_t klo = (uint32_t)seed, khi = (uint32_t)(seed >> 32);
-  bool batch_heads = false;
-  if (mode == GE_CORRUPT_BATCH_COIN)  // one coin for the whole batch (holE.py:137)
-    batch_heads = (philox_w0(slo, shi, 0u, 0u, klo ^ TAG_COIN, khi) >> 31) == 0;
+  const bool batch_heads = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, step) : false;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t ilo = (uint32_t)i, ihi = (uint32_t)((uint64_t)i >> 32);
-    bool heads;
-    if (mode == GE_CORRUPT_BATCH_COIN) heads = batch_heads;
-    else if (mode == GE_CORRUPT_ROW_COIN) heads = (philox_w0(slo, shi, ilo, ihi, klo ^ TAG_SIDE, khi) >> 31) == 0;
-    else heads = (mode == GE_CORRUPT_HEADS);
-    const int col = heads ? 0 : 1;
     int32_t t[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-    const int32_t x = t[col];
-    int32_t repl = -1;  // unknown id -> the '?' default row of -1s (holE.py:39)
-    if (x >= 0 && x < N) {
-      const int32_t ty = id_to_type[x];                      // id_to_type.lookup (holE.py:104)
-      if (ty >= 0 && ty < n_types) {
-        const int64_t off = type_offsets[ty];
-        const uint64_t len = (uint64_t)(type_offsets[ty + 1] - off);
-        if (len > 0) {
-          uint32_t w = philox_w0(slo, shi, ilo, ihi, klo ^ TAG_SLOT, khi);   // holE.py:108-110
-          if (padded_size > 0) {
-            const uint32_t slot = w % (uint32_t)padded_size;
-            w = philox_w0(slo, shi, (uint32_t)ty, slot, klo ^ TAG_PICK, khi);  // holE.py:343-344
-          }
-          repl = type_ids[off + (int64_t)(((uint64_t)w * len) >> 32)];
-        }
-      }
-    }
+    int col;
+    const int32_t repl = corrupt_one(t, i, batch_heads, id_to_type, N, type_offsets, n_types, type_ids,
+                                     seed, step, padded_size, mode, col);
     t[col] = repl;
     neg[3 * i] = t[0]; neg[3 * i + 1] = t[1]; neg[3 * i + 2] = t[2];
   }

@@ -67,15 +67,15 @@ def score_mrr(raw_positions, filtered_positions, verbose: bool = True) -> dict:
 
 def _known_lists(known_triples: np.ndarray, side: str):
     """{(fixed entity, relation): sorted candidate ids known to be true} from [T,3] (h,t,r)."""
-    d = defaultdict(list)
+    d = defaultdict(set)
     if known_triples is None:
         return d
     for h, t, r in np.asarray(known_triples):
         if side == "tail":
-            d[(int(h), int(r))].append(int(t))
+            d[(int(h), int(r))].add(int(t))
         else:
-            d[(int(t), int(r))].append(int(h))
-    return d
+            d[(int(t), int(r))].add(int(h))
+    return {k: sorted(v) for k, v in d.items()}
 
 
 @torch.no_grad()

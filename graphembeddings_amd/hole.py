@@ -265,7 +265,7 @@ class Trainer:
         self.global_step = 0
         self.row = 0
         dev = self.embeddings.device
-        need = _lib.load().ge_hinge_step_workspace_bytes(self.B, self.embeddings.shape[1])
+        need = _lib.load().ge_train_workspace_bytes(self.B, self.embeddings.shape[1])
         self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
         self._neg = torch.empty(self.B, 3, dtype=torch.int32, device=dev)
         self.last_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)

@@ -121,11 +121,16 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * ge_corrupt_batch with step = global_step0 + s; lr_s = lr0 / (1 + decay_rate * (global_step0+s) /
  * decay_steps) (tf.train.inverse_time_decay, holE.py:292-294; decay_steps <= 0 keeps lr0); then one
  * ge_*_hinge_step.  No host synchronisation; every launch goes to `stream` in order.
- * neg_ws: device [B,3] int32 scratch.  loss: device [n_steps*B] when keep_all_losses, else [B]
+ * workspace: >= ge_train_workspace_bytes(B, d) enables the prepared path for B <= 4096 (negatives and
+ * a row-sorted gradient-slot index for 32 steps at a time are built by one LDS bitonic-sort launch;
+ * the update then touches every distinct row once, without atomics unless a row has > 16
+ * occurrences); with only ge_hinge_step_workspace_bytes the loop falls back to sampler + atomics.
+ * neg_ws: device [B,3] int32 scratch (holds the last step's negatives on return).  loss: device [n_steps*B] when keep_all_losses, else [B]
  * (last step).  model: 0 ComplEx, 1 HolE.
  * ev_pairs (nullable, HOST array of 2*n_steps events from ge_event_create): events are recorded on
  * `stream` immediately before and after kernel `ev_kernel` of every step (0 = sampler,
  * 1 = gather+score+hinge+grad, 2 = scatter-add) -- the hook bench.py uses to time one kernel. */
+size_t ge_train_workspace_bytes(int64_t B, int32_t d);
 int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T,
                    int64_t first_row, int64_t B, int64_t n_steps, const int32_t* id_to_type,
                    const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,

@@ -10,10 +10,12 @@ from oracle import hole_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _toy_kg(tmp_path, n_ent=120, n_rel=4, seed=0):
-    """A learnable toy KG: relation r maps entity e -> (e*(r+2)+r) mod n_ent."""
+def _toy_kg(tmp_path, n_ent=120, gsz=6, seed=0):
+    """A learnable toy KG (calibrated on CPU with the oracle: filtered MRR ~0.3 vs chance ~0.04):
+    relation 0 links every ordered pair inside groups of 6 entities (held-out pairs are predictable
+    from the others), relation 1 links entity i of group g to entity i of group g+1."""
     rng = np.random.default_rng(seed)
-    R, N = n_rel, n_rel + n_ent
+    R, N = 2, 2 + n_ent
     rows = [(i, f"r{i}", f"r{i}", "RELATION") for i in range(R)]
     rows += [(R + e, f"e{e}", f"e{e}", "A" if e % 3 else "B") for e in range(n_ent)]
     with open(tmp_path / "entity_metadata.tsv", "w") as f:
@@ -21,12 +23,20 @@ def _toy_kg(tmp_path, n_ent=120, n_rel=4, seed=0):
         for r in rows:
             f.write("\t".join(str(x) for x in r) + "\n")
     (tmp_path / "relation_ids.txt").write_text("".join(f"r{i}\t{i}\n" for i in range(R)))
-    tri = np.array([[R + e, R + (e * (r + 2) + r) % n_ent, r] for e in range(n_ent) for r in range(R)], dtype=np.int64)
-    rng.shuffle(tri)
+    r0, r1 = [], []
+    ng = n_ent // gsz
+    for g in range(ng):
+        mem = [R + g * gsz + i for i in range(gsz)]
+        r0 += [[a, b, 0] for a in mem for b in mem if a != b]
+        r1 += [[R + g * gsz + i, R + ((g + 1) % ng) * gsz + i, 1] for i in range(gsz)]
+    r0 = np.array(r0, dtype=np.int64)
+    rng.shuffle(r0)
     n_test, n_valid = 40, 64
-    np.savetxt(tmp_path / "test_positive_triples.txt", tri[:n_test], fmt="%d", delimiter="\t")
-    np.savetxt(tmp_path / "triples-valid.txt", tri[n_test:n_test + n_valid], fmt="%d", delimiter="\t")
-    np.savetxt(tmp_path / "triples.txt", tri[n_test + n_valid:], fmt="%d", delimiter="\t")
+    train = np.concatenate([r0[n_test + n_valid:], np.array(r1, dtype=np.int64)])
+    rng.shuffle(train)
+    np.savetxt(tmp_path / "test_positive_triples.txt", r0[:n_test], fmt="%d", delimiter="\t")
+    np.savetxt(tmp_path / "triples-valid.txt", r0[n_test:n_test + n_valid], fmt="%d", delimiter="\t")
+    np.savetxt(tmp_path / "triples.txt", train, fmt="%d", delimiter="\t")
     return str(tmp_path)
 
 
@@ -93,7 +103,7 @@ def test_training_driver_end_to_end(tmp_path):
     batch_count = data.triple_count // 64
     assert res["steps"] == 150 * (batch_count - 1)           # an epoch is batch_count-1 steps (holE.py:340)
     assert os.path.exists(T.checkpoint_path(out))
-    assert res["pocket_loss"] < 0.45                          # started at margin 0.5; learning happened
+    assert res["pocket_loss"] < 0.4                          # started at margin 0.5; learning happened
     assert any("Validation Loss" in l for l in logs)
     # the output-dir guard of holE.py:254-255 and --resume_checkpoint
     with pytest.raises(Exception, match="already exists"):
@@ -101,7 +111,7 @@ def test_training_driver_end_to_end(tmp_path):
     FLAGS2 = T.build_parser().parse_args(argv + ["--resume_checkpoint", "--num_epochs", "1"])
     res2 = T.run_training(data, FLAGS2, log=lambda *a: None)
     assert res2["global_step"] > res2["steps"] > 0            # global_step restored (LR decay resumes)
-    # --infer: filtered MRR far above chance (1/120 ~ 0.008 ... random MRR ~ 0.04)
+    # --infer: filtered MRR far above chance (random ranking over 120 candidates: MRR ~ 0.04)
     m = T.infer_triples(T.build_parser().parse_args(argv + ["--infer"]), log=lambda *a: None)
-    assert m["filtered_mrr"] > 0.3 and m["filtered_mrr"] >= m["raw_mrr"]
-    assert m["hits10"] > 50
+    assert m["filtered_mrr"] > 0.15 and m["filtered_mrr"] >= m["raw_mrr"]
+    assert m["hits10"] > 50 and m["mean_filtered_pos"] < 20
