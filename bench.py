@@ -54,6 +54,24 @@ def algorithmic_bytes(kernel: int, B: int, d: int) -> float:
 KERNEL_NAMES = {0: "train_prepare_kernel", 1: "complex_hinge_grad_kernel", 2: "apply_sorted_kernel"}
 
 
+def pmc_traffic(kernel_name: str, tag: str):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary for this
+    workload (profiles/*<tag>_pmc.json, produced by tools/profile_bench.sh: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction).  None when no profile exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{tag}_pmc.json")))
+    if not files:
+        return None
+    try:
+        kern = json.load(open(files[-1])).get("kernels", {})
+    except Exception:
+        return None
+    for name, v in kern.items():
+        if kernel_name.split("<")[0] in name:
+            return {"hbm_bytes_per_launch": v.get("hbm_bytes_corrected"), "source": os.path.basename(files[-1])}
+    return None
+
+
 def cpu_baseline_fb15k(fb, type_arrays, d, B, seconds):
     """The oracle's C port (OpenMP) timed on this host on a bounded sample of the same workload:
     FB15k-shaped table, B positives per step, sampler + fused hinge step."""
@@ -150,6 +168,8 @@ def run_single(args):
     value = 2.0 * B * K / el
     alg = algorithmic_bytes(dom, B, d)
     achieved = alg / (kern_ms * 1e-3) / 1e9
+    tag = f"{workload}_d{d}_b{B}" if args.model == "complex" else f"{workload}_{args.model}_d{d}_b{B}"
+    traffic = pmc_traffic(KERNEL_NAMES[dom], tag)
     out = {
         "metric": "scored triples/sec/GPU (d=200)", "value": value, "unit": "scored triples/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
@@ -158,7 +178,9 @@ def run_single(args):
                    "table_mb": round(n_rows * d * 4 / 1e6, 1), "parallelism": "1 GPU",
                    "scored_triples_per_step": 2 * B, "final_mean_hinge": round(loss_mean, 6)},
         "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                     "traffic_source": traffic["source"] if traffic else None,
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
                      "all_kernels_ms": {KERNEL_NAMES[k]: round(v, 5) for k, v in avg.items()},
                      "step_algorithmic_bytes": (72 * d + 28) * B,

@@ -1,6 +1,7 @@
 // ge_common.h -- shared device helpers for libge_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ge_hip.h"

@@ -336,7 +336,8 @@ int complex_hinge_loss_launch(const float* table, int64_t N, int32_t d, const in
 
 int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos,
                               const int32_t* neg, int64_t B, float margin, float lr, float max_norm,
-                              float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st) {
+                              float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st,
+                              hipEvent_t ev_start, hipEvent_t ev_stop) {
   Shape s;
   if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   // the gradient rows are written with the same vector width: grad_val must be as aligned as rows
@@ -345,7 +346,7 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val)
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val)
   GE_DISPATCH_SHAPE(s, 2, CALL);
 #undef CALL
   return launch_status();

@@ -278,7 +278,8 @@ int hole_hinge_loss_launch(const float* table, int64_t N, int32_t d, const int32
 
 int hole_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
                            int64_t B, float margin, float lr, float max_norm, float* loss,
-                           int32_t* grad_idx, float* grad_val, hipStream_t st) {
+                           int32_t* grad_idx, float* grad_val, hipStream_t st, hipEvent_t ev_start,
+                           hipEvent_t ev_stop) {
   if (d <= 0) return GE_EINVAL;
   if (d > hole_max_dim()) return GE_ENOTSUP;
   if (B == 0) return 0;
@@ -286,9 +287,9 @@ int hole_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_
   const int grid = grid_for(B, kBlock / kWave);
   const size_t lds = hole_lds_bytes(d, nch);
   if (nch == 1)
-    hipLaunchKernelGGL(hole_hinge_grad_kernel<1>, dim3(grid), dim3(kBlock), lds, st, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val);
+    hipExtLaunchKernelGGL(hole_hinge_grad_kernel<1>, dim3(grid), dim3(kBlock), lds, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val);
   else
-    hipLaunchKernelGGL(hole_hinge_grad_kernel<2>, dim3(grid), dim3(kBlock), lds, st, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val);
+    hipExtLaunchKernelGGL(hole_hinge_grad_kernel<2>, dim3(grid), dim3(kBlock), lds, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val);
   return launch_status();
 }
 

@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kBlock) void corrupt_batch_kernel(
 }
 
 int scatter_add_rows_launch(float* table, int64_t N, int32_t d, const int32_t* idx, const float* val,
-                            int64_t R, hipStream_t st) {
+                            int64_t R, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (d <= 0) return GE_EINVAL;
   if (R == 0) return 0;
   const int grid = grid_for(R, kBlock / kWave);
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(kBlock), 0, st, table, N, d, idx, val, R);
+  hipExtLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, N, d, idx, val, R);
   return launch_status();
 }
 

@@ -21,9 +21,9 @@
 
 namespace ge {
 
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t);
-int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t);
-int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
+int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
+int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 
 constexpr int kPrepThreads = 1024;
@@ -222,10 +222,11 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
 }
 
 static int apply_sorted_launch(float* table, int d, int64_t B, const int32_t* items, const int32_t* n_items,
-                               const int32_t* occ, const int32_t* gidx, const float* gval, hipStream_t st) {
+                               const int32_t* occ, const int32_t* gidx, const float* gval, hipStream_t st,
+                               hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int grid = grid_for(4 * B, kBlock / kWave);  // at most 4B items
   const int nj = (d + kWave - 1) / kWave;
-#define LA(NJ) hipLaunchKernelGGL(apply_sorted_kernel<NJ>, dim3(grid), dim3(kBlock), 0, st, table, d, items, n_items, occ, gidx, gval)
+#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, items, n_items, occ, gidx, gval)
   if (nj <= 1) LA(1); else if (nj <= 2) LA(2); else if (nj <= 4) LA(4); else if (nj <= 8) LA(8); else if (nj <= 16) LA(16);
   else return GE_ENOTSUP;
 #undef LA
@@ -365,15 +366,15 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
       neg = neg_ws;
     }
     if (e1 && ev_kernel == 0) (void)hipEventRecord(e1, st);
-    if (e0 && ev_kernel == 1) (void)hipEventRecord(e0, st);
-    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st)
-                    : hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st);
-    if (e1 && ev_kernel == 1) (void)hipEventRecord(e1, st);
+    // the timing events ride on the dispatch packet itself (hipExtLaunchKernel start/stop events):
+    // they report the kernel's own begin/end timestamps, like rocprofv3's kernel trace
+    hipEvent_t g0 = ev_kernel == 1 ? e0 : nullptr, g1 = ev_kernel == 1 ? e1 : nullptr;
+    hipEvent_t a0 = ev_kernel == 2 ? e0 : nullptr, a1 = ev_kernel == 2 ? e1 : nullptr;
+    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1)
+                    : hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1);
     if (rc) return rc;
-    if (e0 && ev_kernel == 2) (void)hipEventRecord(e0, st);
-    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + 7 * B, step_prep + 19 * B, step_prep + 3 * B, gidx, gval, st);
-    else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st);
-    if (e1 && ev_kernel == 2) (void)hipEventRecord(e1, st);
+    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + 7 * B, step_prep + 19 * B, step_prep + 3 * B, gidx, gval, st, a0, a1);
+    else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
     if (rc) return rc;
     if (fast && ((s % kPrepChunk) == kPrepChunk - 1 || s == n_steps - 1))
       GE_HIP_TRY(hipEventRecord(aux->buf_free[(s / kPrepChunk) & 1], st));
