@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--model", default="complex", choices=["complex", "hole"])
     ap.add_argument("--sharded", action="store_true", help="run the row-sharded (all-to-all) path even on 1 GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-score-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--entities", type=int, default=1_200_000)
     ap.add_argument("--triples", type=int, default=30_000_000)
@@ -70,6 +71,36 @@ def pmc_traffic(kernel_name: str, tag: str):
         if kernel_name.split("<")[0] in name:
             return {"hbm_bytes_per_launch": v.get("hbm_bytes_corrected"), "source": os.path.basename(files[-1])}
     return None
+
+
+def score_kernel_roofline(d, n_rows=1_200_018, n_triples=1 << 22, iters=10):
+    """The kernel north_star sets the >=70 %-of-HBM target on: the fused gather + ComplEx score
+    (ge_complex_score) at d=200, measured where it is HBM-bound -- a 960 MB table (> 256 MB Infinity
+    Cache), uniformly random rows, 4 M triples per launch.  Algorithmic bytes 12d+16 per scored triple
+    (SURVEY.md 8d).  Supplementary to `roofline` (which is the dominant kernel of the timed train step)."""
+    import torch
+    from graphembeddings_amd import hole as H
+    g = torch.Generator(device="cuda").manual_seed(0)
+    table = torch.randn(n_rows, d, device="cuda", generator=g) * 0.05
+    tr = torch.randint(0, n_rows, (n_triples, 3), device="cuda", generator=g, dtype=torch.int32)
+    for _ in range(2):
+        H.evaluate_triples(tr, table)
+    torch.cuda.synchronize()
+    ev = H.Events(2)
+    ev.record(0)
+    for _ in range(iters):
+        H.evaluate_triples(tr, table)
+    ev.record(1)
+    torch.cuda.synchronize()
+    ms = ev.elapsed_ms(0, 1) / iters
+    ev.close()
+    alg = (12 * d + 16) * n_triples
+    achieved = alg / (ms * 1e-3) / 1e9
+    del table, tr
+    return {"kernel": "complex_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "kernel_ms": ms, "triples_per_launch": n_triples,
+            "table_rows": n_rows, "table_mb": round(n_rows * d * 4 / 1e6, 1),
+            "scored_triples_per_s": n_triples / (ms * 1e-3), "algorithmic_bytes_per_launch": alg}
 
 
 def cpu_baseline_fb15k(fb, type_arrays, d, B, seconds):
@@ -186,6 +217,8 @@ def run_single(args):
                      "step_algorithmic_bytes": (72 * d + 28) * B,
                      "step_achieved_GBs": (72 * d + 28) * B / (el / K) / 1e9},
     }
+    if not args.no_score_roofline:
+        out["score_kernel_roofline"] = score_kernel_roofline(d)
     if not args.no_cpu_baseline and workload == "fb15k":
         out["cpu_baseline"] = cpu_baseline_fb15k(fb, arrays, d, B, args.cpu_seconds)
     elif not args.no_cpu_baseline:

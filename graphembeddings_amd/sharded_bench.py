@@ -66,20 +66,32 @@ def run(args):
         return out
     timed_grad.pending = False
 
-    def one_step(i):
-        row = (i * B) % (n_loc - B)
-        lr = H.inverse_time_decay(0.1, tr.global_step, decay_steps, 0.5)
-        return tr.step(dtri[row:row + B], lr)
+    CHUNK = 16   # steps planned per exchange plan (one dedup / count exchange / host sync per chunk)
 
-    for i in range(W):
-        loss = one_step(i)
+    def lr_fn(gs):
+        return H.inverse_time_decay(0.1, gs, decay_steps, 0.5)
+
+    def run_steps(first, n):
+        out = None
+        i = first
+        while i < first + n:
+            m = min(CHUNK, first + n - i)
+            rows = [((j * B) % (n_loc - B)) for j in range(i, i + m)]
+            pos = torch.stack([dtri[r:r + B] for r in rows], 0)
+            out = tr.run(pos, lr_fn)[-1]
+            i += m
+        return out
+
+    def one_step(i):
+        return run_steps(i, 1)
+
+    loss = run_steps(0, W)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(W, W + K):
-        loss = one_step(i)
+    loss = run_steps(W, K)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -79,9 +79,10 @@ def _worker(rank, world, port, q):
                               kernels=OracleKernels())
         B = len(pos)
         mine = torch.as_tensor(pos[rank * B // world:(rank + 1) * B // world])
-        losses = []
-        for step in range(3):                 # several steps: updates must be visible to later fetches
-            losses.append(tr.step(mine, lr=0.05))
+        # one planned chunk of 2 steps (ids / counts / remaps exchanged once for both), then a single
+        # step: updates of earlier steps must be visible to later fetches
+        chunk = tr.run(torch.stack([mine, mine], 0), lambda gs: 0.05)
+        losses = [chunk[0], chunk[1], tr.step(mine, lr=0.05)]
         out = tr.gather_full_table()
         mean = tr.mean_loss(losses[-1])
         if rank == 0:
