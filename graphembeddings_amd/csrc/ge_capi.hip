@@ -16,6 +16,7 @@ int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const floa
 int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float*, hipStream_t);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
+int bernoulli_corrupt_launch(const int32_t*, int64_t, const int64_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, const uint32_t*, int32_t, int32_t, int32_t, uint64_t, uint64_t, int32_t*, hipStream_t);
 size_t hinge_ws_bytes(int64_t, int32_t);
 size_t train_ws_bytes(int64_t, int32_t);
 int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, hipStream_t);
@@ -126,6 +127,17 @@ int ge_corrupt_batch(const int32_t* pos, int64_t B, const int32_t* id_to_type, i
   if (B > 0 && (!pos || !neg)) return GE_EINVAL;
   return corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, step,
                               padded_size, mode, neg, (hipStream_t)stream);
+}
+
+int ge_bernoulli_corrupt_batch(const int32_t* pos, int64_t B, const int64_t* bh_key, const int32_t* bh_ent,
+                               const int64_t* bt_key, const int32_t* bt_ent, int64_t n_known,
+                               const uint32_t* tail_threshold, int32_t n_rel, int32_t ent_lo, int32_t n_ent,
+                               uint64_t seed, uint64_t step, int32_t* neg, void* stream) {
+  if (B < 0 || !tail_threshold) return GE_EINVAL;
+  if (n_known > 0 && (!bh_key || !bh_ent || !bt_key || !bt_ent)) return GE_EINVAL;
+  if (B > 0 && (!pos || !neg)) return GE_EINVAL;
+  return bernoulli_corrupt_launch(pos, B, bh_key, bh_ent, bt_key, bt_ent, n_known, tail_threshold, n_rel,
+                                  ent_lo, n_ent, seed, step, neg, (hipStream_t)stream);
 }
 
 int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,

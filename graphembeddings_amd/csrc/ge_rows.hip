@@ -64,6 +64,86 @@ __global__ __launch_bounds__(kBlock) void corrupt_batch_kernel(
   }
 }
 
+// ---------------------------------------------------------------- Bernoulli filtered sampler
+// GPU form of the reference's native sampler init.so (init.cpp:159-246): the side to corrupt is
+// chosen per triple with P(tail) = hpt/(hpt+tph) of its relation (init.cpp:226-228) and the
+// replacement is drawn uniformly among the entities that do NOT complete a known triple, by mapping
+// tmp in [0, E - cnt) past the sorted known entities of the (fixed entity, relation) key with a
+// binary search (init.cpp:177-188).  One thread per triple, per-row Philox draws instead of the
+// reference's single global LCG (init.cpp:145-150); the two init.cpp defects (sizeof(pointer) memset,
+// `j < rig` loop bound) live in the host-side statistics and are fixed there.
+__device__ __forceinline__ int64_t lower_bound64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int64_t upper_bound64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+#define GE_TAG_BSIDE 0x62736964u
+#define GE_TAG_BPICK 0x62706963u
+
+__global__ __launch_bounds__(kBlock) void bernoulli_corrupt_kernel(
+    const int32_t* __restrict__ pos, int64_t B, const int64_t* __restrict__ bh_key,
+    const int32_t* __restrict__ bh_ent, const int64_t* __restrict__ bt_key,
+    const int32_t* __restrict__ bt_ent, int64_t n_known, const uint32_t* __restrict__ tail_threshold,
+    int32_t n_rel, int32_t ent_lo, int32_t n_ent, uint64_t seed, uint64_t step, int32_t* __restrict__ neg) {
+  const uint32_t slo = (uint32_t)step, shi = (uint32_t)(step >> 32);
+  const uint32_t klo = (uint32_t)seed, khi = (uint32_t)(seed >> 32);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t t[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+    const int32_t r = t[2];
+    if (r < 0 || r >= n_rel) { neg[3 * i] = -1; neg[3 * i + 1] = -1; neg[3 * i + 2] = -1; continue; }
+    const uint32_t ilo = (uint32_t)i, ihi = (uint32_t)((uint64_t)i >> 32);
+    const uint32_t w_side = philox_w0(slo, shi, ilo, ihi, klo ^ GE_TAG_BSIDE, khi);
+    const uint32_t w_pick = philox_w0(slo, shi, ilo, ihi, klo ^ GE_TAG_BPICK, khi);
+    const bool tail_side = w_side < tail_threshold[r];
+    const int64_t* key_arr = tail_side ? bh_key : bt_key;
+    const int32_t* ent_arr = tail_side ? bh_ent : bt_ent;
+    const int64_t key = (int64_t)(tail_side ? t[0] : t[1]) * n_rel + r;
+    const int col = tail_side ? 1 : 0;
+    const int64_t ll = lower_bound64(key_arr, n_known, key);
+    const int64_t rr = upper_bound64(key_arr, n_known, key) - 1;
+    const int64_t cnt = rr >= ll ? rr - ll + 1 : 0;
+    const int64_t free_n = (int64_t)n_ent - cnt;
+    int32_t repl = -1;
+    if (free_n > 0) {
+      const int64_t tmp = (int64_t)(((uint64_t)w_pick * (uint64_t)free_n) >> 32);
+      int64_t j;
+      if (cnt == 0) j = tmp;
+      else if (tmp < (int64_t)ent_arr[ll] - ent_lo) j = tmp;
+      else if (tmp > (int64_t)ent_arr[rr] - ent_lo - rr + ll - 1) j = tmp + rr - ll + 1;
+      else {
+        int64_t lef = ll, rig = rr + 1;
+        while (lef + 1 < rig) {
+          const int64_t mid = (lef + rig) >> 1;
+          if ((int64_t)ent_arr[mid] - ent_lo - mid + ll - 1 < tmp) lef = mid; else rig = mid;
+        }
+        j = tmp + lef - ll + 1;
+      }
+      repl = ent_lo + (int32_t)j;
+    }
+    t[col] = repl;
+    neg[3 * i] = t[0]; neg[3 * i + 1] = t[1]; neg[3 * i + 2] = t[2];
+  }
+}
+
+int bernoulli_corrupt_launch(const int32_t* pos, int64_t B, const int64_t* bh_key, const int32_t* bh_ent,
+                             const int64_t* bt_key, const int32_t* bt_ent, int64_t n_known,
+                             const uint32_t* tail_threshold, int32_t n_rel, int32_t ent_lo, int32_t n_ent,
+                             uint64_t seed, uint64_t step, int32_t* neg, hipStream_t st) {
+  if (n_known < 0 || n_rel <= 0 || n_ent <= 0) return GE_EINVAL;
+  if (B == 0) return 0;
+  const int grid = grid_for(B, kBlock);
+  hipLaunchKernelGGL(bernoulli_corrupt_kernel, dim3(grid), dim3(kBlock), 0, st, pos, B, bh_key, bh_ent, bt_key,
+                     bt_ent, n_known, tail_threshold, n_rel, ent_lo, n_ent, seed, step, neg);
+  return launch_status();
+}
+
 int scatter_add_rows_launch(float* table, int64_t N, int32_t d, const int32_t* idx, const float* val,
                             int64_t R, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (d <= 0) return GE_EINVAL;

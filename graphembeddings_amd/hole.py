@@ -332,3 +332,38 @@ class Events:
         for h in self.handles:
             _lib.load().ge_event_destroy(h)
         self.handles = []
+
+
+class BernoulliSampler:
+    """Filtered Bernoulli negative sampler: the GPU form of the reference's native init.so
+    (init.cpp:159-246) for tables that share relation and entity rows (holE.py layout: entities are
+    rows [relation_count, entity_count)).  Known triples -> two sorted device indexes + per-relation
+    tail-corruption thresholds from tails-per-head / heads-per-tail (init.cpp:107-127, defects fixed)."""
+
+    def __init__(self, known_triples: np.ndarray, relation_count: int, entity_count: int, device="cuda"):
+        tri = np.unique(np.asarray(known_triples, dtype=np.int64), axis=0)
+        R = int(relation_count)
+        self.n_rel, self.ent_lo, self.n_ent = R, R, int(entity_count) - R
+        bh = tri[np.lexsort((tri[:, 1], tri[:, 2], tri[:, 0]))]
+        bt = tri[np.lexsort((tri[:, 0], tri[:, 2], tri[:, 1]))]
+        freq = np.bincount(tri[:, 2], minlength=R).astype(np.float64)
+        n_hr = np.bincount(np.unique(tri[:, [0, 2]], axis=0)[:, 1], minlength=R).astype(np.float64)
+        n_tr = np.bincount(np.unique(tri[:, [1, 2]], axis=0)[:, 1], minlength=R).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tph = np.where(n_hr > 0, freq / n_hr, 1.0)
+            hpt = np.where(n_tr > 0, freq / n_tr, 1.0)
+        thr = np.minimum(np.floor(hpt / (hpt + tph) * 4294967296.0), 4294967295.0).astype(np.uint32)
+        to = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a.astype(dt))).to(device)
+        self.bh_key, self.bh_ent = to(bh[:, 0] * R + bh[:, 2], np.int64), to(bh[:, 1], np.int32)
+        self.bt_key, self.bt_ent = to(bt[:, 1] * R + bt[:, 2], np.int64), to(bt[:, 0], np.int32)
+        self.tail_threshold = torch.as_tensor(thr.view(np.int32)).to(device)   # bit pattern of the uint32s
+        self.n_known = int(len(tri))
+
+    def corrupt(self, triples: torch.Tensor, *, seed: int = 0, step: int = 0) -> torch.Tensor:
+        tb = _triples(triples, "triples")
+        neg = torch.empty_like(tb)
+        _lib.call("ge_bernoulli_corrupt_batch", tb.data_ptr(), tb.shape[0], self.bh_key.data_ptr(),
+                  self.bh_ent.data_ptr(), self.bt_key.data_ptr(), self.bt_ent.data_ptr(), self.n_known,
+                  self.tail_threshold.data_ptr(), self.n_rel, self.ent_lo, self.n_ent,
+                  int(seed) & (2**64 - 1), int(step) & (2**64 - 1), neg.data_ptr(), _stream())
+        return neg

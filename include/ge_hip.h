@@ -105,6 +105,21 @@ int ge_corrupt_batch(const int32_t* pos, int64_t B, const int32_t* id_to_type, i
                      uint64_t seed, uint64_t step, int32_t padded_size, int32_t mode, int32_t* neg,
                      void* stream);
 
+/* --- Bernoulli filtered corruption: GPU form of the reference's native TransX sampler init.so
+ * (getBatch / corrupt_head / corrupt_tail, init.cpp:159-246; tph/hpt statistics init.cpp:107-127).
+ * Known triples are given as two sorted indexes: bh_* sorted by (head, relation, tail) with
+ * bh_key = head*n_rel + relation and bh_ent = tail; bt_* sorted by (tail, relation, head) likewise.
+ * tail_threshold[r] = floor(2^32 * hpt_r / (hpt_r + tph_r)): a row corrupts its TAIL iff a uniform
+ * 32-bit word is below it, else its head (init.cpp:226-228).  The replacement is uniform over the
+ * entities [ent_lo, ent_lo+n_ent) that do not complete a known triple (filtered, init.cpp:177-188).
+ * Unlike init.so (void returns, one global LCG, not thread-safe) this is stateless: per-row
+ * Philox4x32-10 draws keyed by (seed, step, row); oracle/transx_oracle.py states the stream and is
+ * itself pinned against the compiled init.cpp. */
+int ge_bernoulli_corrupt_batch(const int32_t* pos, int64_t B, const int64_t* bh_key, const int32_t* bh_ent,
+                               const int64_t* bt_key, const int32_t* bt_ent, int64_t n_known,
+                               const uint32_t* tail_threshold, int32_t n_rel, int32_t ent_lo,
+                               int32_t n_ent, uint64_t seed, uint64_t step, int32_t* neg, void* stream);
+
 /* --- 1-vs-K candidate scoring (the inference loop of holE.py:564-569: fixed (head, relation)
  * against many tails; also K shared negatives per positive).  hr: [B,2] int32 (fixed entity,
  * relation); cand: [K] int32 candidate entity rows; cand_is_head = 0 scores (fixed, cand_j, rel),

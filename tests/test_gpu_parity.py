@@ -388,3 +388,27 @@ def test_train_steps_fast_path_is_reproducible(H):
         torch.cuda.synchronize()
         outs.append(emb)
     assert torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------- Bernoulli filtered sampler (init.cpp)
+def test_bernoulli_sampler_bit_exact_vs_pinned_oracle(H):
+    from oracle import transx_oracle as TO
+    rng = np.random.default_rng(4)
+    R, E, T = 9, 500, 6000
+    lo = R
+    tri = np.unique(np.stack([lo + rng.integers(0, E, T), lo + rng.integers(0, E, T), rng.integers(0, R, T)], 1), axis=0)
+    tri[:200, 0] = lo + 3                         # one head with hundreds of known (r, t)
+    tri = np.unique(tri, axis=0)
+    idx = TO.BernoulliIndex(tri, lo, E, R)
+    smp = H.BernoulliSampler(tri, R, R + E)
+    assert np.array_equal(smp.tail_threshold.cpu().numpy().view(np.uint32), idx.tail_threshold)
+    pos = tri[rng.integers(0, len(tri), 3000)].astype(np.int32)
+    pos[5] = [lo + 1, lo + 2, 3]                  # may be an unknown triple: unfiltered uniform draw
+    pos[6, 2] = R + 4                             # invalid relation -> all -1
+    for (seed, step) in ((0, 0), (123456789012345, 2**33 + 5)):
+        neg = smp.corrupt(dev(pos), seed=seed, step=step).cpu().numpy()
+        exp = TO.bernoulli_corrupt_batch(pos, idx, seed, step)
+        assert np.array_equal(neg, exp)
+    known = {tuple(x) for x in tri}
+    ok = neg[:, 2] >= 0
+    assert not any(tuple(int(v) for v in row) in known for row in neg[ok])
