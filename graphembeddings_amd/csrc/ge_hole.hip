@@ -29,6 +29,7 @@ __device__ __forceinline__ void corr4(const float* __restrict__ a, const float* 
                                       int k0, float (&c)[4]) {
   c[0] = c[1] = c[2] = c[3] = 0.f;
   const float* bk = b + k0;
+#pragma unroll 2
   for (int i = 0; i < d4; i += 4) {
     const float4 av = *reinterpret_cast<const float4*>(a + i);
     const float4 b0 = *reinterpret_cast<const float4*>(bk + i);
@@ -39,6 +40,30 @@ __device__ __forceinline__ void corr4(const float* __restrict__ a, const float* 
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int q = 0; q < 4; ++q) c[q] += aa[u] * bb[u + q];
+  }
+}
+
+// Two correlations against the same doubled operand b in one pass (shares the b reads):
+// c1[q] += sum_i a1[i] b[i+k0+q],  c2[q] += sum_i a2[i] b[i+k0+q]   -- 4 LDS reads per 32 FMAs.
+__device__ __forceinline__ void corr4x2(const float* __restrict__ a1, const float* __restrict__ a2,
+                                        const float* __restrict__ b, int d4, int k0, float (&c1)[4],
+                                        float (&c2)[4]) {
+  c1[0] = c1[1] = c1[2] = c1[3] = 0.f;
+  c2[0] = c2[1] = c2[2] = c2[3] = 0.f;
+  const float* bk = b + k0;
+#pragma unroll 2
+  for (int i = 0; i < d4; i += 4) {
+    const float4 u = *reinterpret_cast<const float4*>(a1 + i);
+    const float4 v = *reinterpret_cast<const float4*>(a2 + i);
+    const float4 b0 = *reinterpret_cast<const float4*>(bk + i);
+    const float4 b1 = *reinterpret_cast<const float4*>(bk + i + 4);
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float uu[4] = {u.x, u.y, u.z, u.w};
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { c1[q] += uu[w] * bb[w + q]; c2[q] += vv[w] * bb[w + q]; }
   }
 }
 
@@ -79,13 +104,14 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
   for (int c = 0; c < NCH; ++c) {
     const int k0 = c * 256 + 4 * lane;
     if (k0 < d4) {
-      corr4(a_h, b_t, d4, k0, Gr[c]);  // (h star t): d s/d r, and the score itself
+      if (GRAD) {
+        corr4x2(a_h, a_r, b_t, d4, k0, Gr[c], Gh[c]);  // (h star t) = ds/dr and (r star t) = ds/dh
+        corr4(a_rr, b_h, d4, k0, Gt[c]);               // (rev r star h) = ds/dt
+      } else {
+        corr4(a_h, b_t, d4, k0, Gr[c]);                // (h star t): the score
+      }
       const float4 rv = *reinterpret_cast<const float4*>(a_r + k0);
       part += rv.x * Gr[c][0] + rv.y * Gr[c][1] + rv.z * Gr[c][2] + rv.w * Gr[c][3];
-      if (GRAD) {
-        corr4(a_r, b_t, d4, k0, Gh[c]);   // (r star t): d s/d h
-        corr4(a_rr, b_h, d4, k0, Gt[c]);  // (rev r star h): d s/d t
-      }
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { Gr[c][q] = 0.f; Gh[c][q] = 0.f; Gt[c][q] = 0.f; }

@@ -115,3 +115,30 @@ def test_training_driver_end_to_end(tmp_path):
     m = T.infer_triples(T.build_parser().parse_args(argv + ["--infer"]), log=lambda *a: None)
     assert m["filtered_mrr"] > 0.15 and m["filtered_mrr"] >= m["raw_mrr"]
     assert m["hits10"] > 50 and m["mean_filtered_pos"] < 20
+
+
+def test_fb15k_scale_ranks_match_oracle_on_real_id_files():
+    """FB15k id space (real entity_metadata / valid / test files shipped with the package): raw and
+    filtered tail ranks over all 14,951 entities from the MFMA candidate sweep equal the reference's
+    heap semantics (holE.py:427-472) evaluated by the oracle on the same scores."""
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import evaluate as E
+    from graphembeddings_amd import hole as H
+    inf = D.init_inference_data(D.PACKAGE_FB15K_DIR)
+    assert inf.entity_count == 16296 and len(inf.test_array) == 59071
+    emb = H.init_embeddings(inf.entity_count, 200, seed=3) * 4.0
+    R, N = inf.relation_count, inf.entity_count
+    cand = np.arange(R, N, dtype=np.int32)
+    test = inf.test_array[:40]
+    known = inf.validation_triples
+    raw, fil = E.link_prediction_ranks(emb, test, cand, known, side="tail", batch=16)
+    true = O.triple_dict(known)
+    for i, (h, t, r) in enumerate(test):
+        hr = torch.as_tensor(np.array([[h, r]], dtype=np.int32)).cuda()
+        s = H.score_candidates(emb, hr, torch.as_tensor(cand).cuda())[0].cpu().numpy()
+        triples = np.stack([np.full(len(cand), h), cand, np.full(len(cand), r)], 1)
+        rp, fp = [], []
+        O.eval_link_prediction(s, triples, true, O.triple_dict([[h, t, r]]), rp, fp)
+        assert [raw[i]] == rp and [fil[i]] == fp
+    m = E.score_mrr(raw, fil, verbose=False)
+    assert 0 < m["filtered_mrr"] <= 1 and m["filtered_mrr"] >= m["raw_mrr"]
