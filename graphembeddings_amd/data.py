@@ -56,6 +56,28 @@ def read_triples(path: str) -> np.ndarray:
     return np.ascontiguousarray(df.to_numpy(dtype=np.int32))
 
 
+def read_triples_cached(path: str) -> np.ndarray:
+    """read_triples with a binary side-car: `<file>.npy` (int32 [T,3]) is written next to the TSV on
+    first use and memory-mapped afterwards when it is newer than the TSV.  Parsing 30 M-250 M-triple
+    TSVs (README.md:60,120) is otherwise the start-up bottleneck once the kernels are fast."""
+    cache = path + ".npy"
+    try:
+        if os.path.exists(cache) and os.path.getmtime(cache) >= os.path.getmtime(path):
+            arr = np.load(cache, mmap_mode="r")
+            if arr.ndim == 2 and arr.shape[1] == 3 and arr.dtype == np.int32:
+                return arr
+    except Exception:
+        pass
+    arr = read_triples(path)
+    try:
+        tmp = cache + ".tmp.npy"
+        np.save(tmp, arr)
+        os.replace(tmp, cache)
+    except OSError:
+        pass  # read-only data dir: keep going without the cache
+    return arr
+
+
 def write_triples(path: str, triples: np.ndarray) -> None:
     np.savetxt(path, np.asarray(triples, dtype=np.int64), fmt="%d", delimiter="\t")
 
@@ -114,7 +136,7 @@ def _read_metadata(entity_file: str, data: HolEData, min_mentions: Optional[int]
             data.id_to_metadata[index] = ent_id + " " + name
 
 
-def init_data(data_dir: str, require_train: bool = True) -> HolEData:
+def init_data(data_dir: str, require_train: bool = True, cache: bool = False) -> HolEData:
     """Model pre-processing (init_data, holE.py:44-94) without the TF input queues: the triple files
     are parsed once into int32 arrays; batching is done by TripleBatcher."""
     entity_file = _resolve(os.path.join(data_dir, "entity_metadata.tsv"))
@@ -130,7 +152,7 @@ def init_data(data_dir: str, require_train: bool = True) -> HolEData:
     data.relation_count = count_lines(relation_file)
     _read_metadata(entity_file, data)
     if train_file is not None:
-        data.triples = read_triples(train_file)
+        data.triples = (read_triples_cached if cache else read_triples)(train_file)
         data.triple_count = int(data.triples.shape[0])
     if valid_file is not None:
         data.validation_triples = read_triples(valid_file)

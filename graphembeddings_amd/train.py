@@ -97,7 +97,7 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
             raise ValueError('checkpoint shape does not match the data / --embedding_dim')
     else:
         embeddings = H.init_embeddings(data.entity_count, FLAGS.embedding_dim, seed=FLAGS.seed)
-    triples = torch.as_tensor(data.triples).cuda()
+    triples = torch.as_tensor(np.ascontiguousarray(data.triples)).cuda()
     trainer = H.Trainer(embeddings, triples, tt, FLAGS.batch_size, margin=FLAGS.margin,
                         learning_rate=FLAGS.learning_rate,
                         decay_steps=FLAGS.learning_decay_steps * batch_count,
@@ -178,7 +178,7 @@ def main(argv=None):
     elif FLAGS.infer:
         infer_triples(FLAGS)
     else:
-        training_data = D.init_data(FLAGS.data_dir)
+        training_data = D.init_data(FLAGS.data_dir, cache=True)
         print('Entities: ', training_data.entity_count - training_data.relation_count, 'Relations: ',
               training_data.relation_count, 'Triples: ', training_data.triple_count)
         run_training(training_data, FLAGS)

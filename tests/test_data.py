@@ -108,3 +108,15 @@ def test_batcher_and_synthetic(fb):
     assert data.entity_count == 5018 and tri.shape == (20000, 3) and len(names) == 13
     assert (id_to_type[ids[offsets[1]:offsets[2]]] == 1).all()
     assert (np.diff(offsets)[1] / 5000) > 0.98
+
+
+def test_binary_triple_cache(tmp_path):
+    p = _write_dir(tmp_path, False)
+    a = D.init_data(p, cache=True).triples
+    assert (tmp_path / "triples.txt.npy").exists()
+    b = D.init_data(p, cache=True).triples          # second load comes from the memory-mapped cache
+    assert np.array_equal(a, b) and b.dtype == np.int32
+    (tmp_path / "triples.txt").write_text("2\t4\t0\n")   # TSV newer than the cache -> re-parsed
+    import os, time
+    os.utime(tmp_path / "triples.txt", (time.time() + 5, time.time() + 5))
+    assert D.init_data(p, cache=True).triples.tolist() == [[2, 4, 0]]
