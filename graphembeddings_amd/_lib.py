@@ -33,6 +33,7 @@ SYMBOLS = {
     "ge_bernoulli_corrupt_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _u64, _u64, _p, _p]),
     "ge_complex_score_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _f, C.c_int, C.c_int, _p, _p]),
     "ge_train_workspace_bytes": (_sz, [_i64, _i32]),
+    "ge_set_fused_step": (C.c_int, [C.c_int]),
     "ge_train_steps": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _i64, _i64, _p, _p, _i32, _p, _u64, _u64, _i32,
                                  _i32, _f, _f, _f, _f, _f, C.c_int, _p, C.c_int, _p, _p, _sz, _p, C.c_int, _p]),
     "ge_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),

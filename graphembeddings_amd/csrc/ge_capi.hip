@@ -6,7 +6,7 @@
 namespace ge {
 int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
 int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr);
 int complex_max_dim();
 int hole_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
 int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
@@ -19,6 +19,7 @@ int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int
 int bernoulli_corrupt_launch(const int32_t*, int64_t, const int64_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, const uint32_t*, int32_t, int32_t, int32_t, uint64_t, uint64_t, int32_t*, hipStream_t);
 size_t hinge_ws_bytes(int64_t, int32_t);
 size_t train_ws_bytes(int64_t, int32_t);
+int set_fused_step(int);
 int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, hipStream_t);
 }  // namespace ge
 
@@ -169,6 +170,8 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
                          max_norm, model, loss, keep_all_losses, neg_ws, workspace, workspace_bytes, ev_pairs,
                          ev_kernel, (hipStream_t)stream);
 }
+
+int ge_set_fused_step(int on) { return set_fused_step(on); }
 
 int ge_event_create(void** ev) {
   if (!ev) return GE_EINVAL;

@@ -15,86 +15,9 @@
 // The clip is a per-row scalar and the score is trilinear, so s = sh*st*sr*s_raw and, by Euler's
 // identity for a trilinear form, (d s/d y_X) . x_X = s / scale_X: the backward pass through the
 // clip needs no reduction beyond the forward ones.
-#include "ge_common.h"
+#include "ge_complex_dev.h"
 
 namespace ge {
-
-template <int VEC, int NITER>
-struct Row {
-  float re[NITER][VEC];
-  float im[NITER][VEC];
-};
-
-template <int VEC, int LPT, int NITER>
-__device__ __forceinline__ void load_row(const float* __restrict__ rows, int32_t id, int d, int k,
-                                         int nvec, int sub, Row<VEC, NITER>& R) {
-  const float* p = rows + (int64_t)id * d;
-#pragma unroll
-  for (int it = 0; it < NITER; ++it) {
-    const int j = sub + it * LPT;
-    if (j < nvec) {
-      load_vec<VEC>(p + j * VEC, R.re[it]);
-      load_vec<VEC>(p + k + j * VEC, R.im[it]);
-    } else {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) { R.re[it][v] = 0.f; R.im[it][v] = 0.f; }
-    }
-  }
-}
-
-template <int VEC, int NITER>
-__device__ __forceinline__ float row_sumsq(const Row<VEC, NITER>& R) {
-  float ss = 0.f;
-#pragma unroll
-  for (int it = 0; it < NITER; ++it)
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) ss += R.re[it][v] * R.re[it][v] + R.im[it][v] * R.im[it][v];
-  return ss;
-}
-
-// lane-partial of sum_k Re(h_k r_k conj(t_k)) = a(ce+df) + b(cf-de)   (holE.py:191-192)
-template <int VEC, int NITER>
-__device__ __forceinline__ float raw_score(const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
-                                           const Row<VEC, NITER>& r) {
-  float s = 0.f;
-#pragma unroll
-  for (int it = 0; it < NITER; ++it)
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const float a = h.re[it][v], b = h.im[it][v], e = t.re[it][v], f = t.im[it][v];
-      const float c = r.re[it][v], dd = r.im[it][v];
-      s += a * (c * e + dd * f) + b * (c * f - dd * e);
-    }
-  return s;
-}
-
-struct SideFwd {
-  float s_raw;             // score of the un-clipped rows
-  float sc[3];             // clip scales h,t,r
-  float inv[3];            // rsqrt(sum x^2) h,t,r
-  float sig;               // sigma(s)
-  float s;                 // clipped score
-};
-
-template <int VEC, int LPT, int NITER>
-__device__ __forceinline__ SideFwd side_forward(const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
-                                                const Row<VEC, NITER>& r, float max_norm) {
-  SideFwd o;
-  const float ssh = group_sum<LPT>(row_sumsq(h));
-  const float sst = group_sum<LPT>(row_sumsq(t));
-  const float ssr = group_sum<LPT>(row_sumsq(r));
-  o.s_raw = group_sum<LPT>(raw_score(h, t, r));
-  o.sc[0] = clip_scale(ssh, max_norm, o.inv[0]);
-  o.sc[1] = clip_scale(sst, max_norm, o.inv[1]);
-  o.sc[2] = clip_scale(ssr, max_norm, o.inv[2]);
-  o.s = o.s_raw * o.sc[0] * o.sc[1] * o.sc[2];
-  o.sig = sigmoidf_dev(o.s);
-  return o;
-}
-
-__device__ __forceinline__ bool bad3(int64_t N, int32_t a, int32_t b, int32_t c) {
-  return a < 0 || b < 0 || c < 0 || a >= N || b >= N || c >= N;
-}
 
 // ---------------------------------------------------------------- evaluate_triples
 template <int VEC, int LPT, int NITER>
@@ -165,42 +88,23 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
 // h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
 // rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
-struct RowCoef { float alpha, beta; };
-
-__device__ __forceinline__ RowCoef row_coef(float coef, const SideFwd& f, int X, float max_norm,
-                                            float neg_lr) {
-  const float P = (X == 0 ? f.sc[1] * f.sc[2] : X == 1 ? f.sc[0] * f.sc[2] : f.sc[0] * f.sc[1]);
-  const float A = coef * P;
-  const float inv = f.inv[X];
-  const bool active = inv <= 1.0f / max_norm;
-  RowCoef c;
-  c.alpha = neg_lr * (active ? max_norm * A * inv : A);
-  c.beta = active ? neg_lr * (-max_norm * A * f.s_raw * inv * inv * inv) : 0.f;
-  return c;
-}
-
-// raw bilinear gradients of s_raw wrt X for one lane slice
-template <int VEC, int NITER>
-__device__ __forceinline__ void graw(int X, const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
-                                     const Row<VEC, NITER>& r, int it, int v, float& gre, float& gim) {
-  const float a = h.re[it][v], b = h.im[it][v], e = t.re[it][v], f = t.im[it][v];
-  const float c = r.re[it][v], dd = r.im[it][v];
-  if (X == 0) { gre = c * e + dd * f; gim = c * f - dd * e; }        // d/dh
-  else if (X == 1) { gre = a * c - b * dd; gim = a * dd + b * c; }   // d/dt
-  else { gre = a * e + b * f; gim = a * f - b * e; }                 // d/dr
-}
-
 template <int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
-    float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val) {
+    float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
+    const int32_t* __restrict__ slot_item) {
+  // slot_item (training loop only, else null): a slot tagged kSlotDirect is the ONLY gradient slot
+  // of its table row in this step -- this pair is the row's only reader and writer -- so the update is
+  // applied right here (rows + (-lr*g)) and no gradient row is written for it.
+  constexpr int kSlotDirect = -2;
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int k = d >> 1, nvec = k / VEC;
   const float neg_lr = -lr;
+  float* const table_rw = const_cast<float*>(rows);
   for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
     const int64_t g = base + grp;
     const bool live = g < B;
@@ -226,15 +130,17 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     for (int X = 0; X < 3; ++X) {
       const bool same = p[X] == n[X];
       const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
+      const bool dirP = slot_item && live && slot_item[rowP] == kSlotDirect;
+      const bool dirN = slot_item && live && !same && slot_item[rowN] == kSlotDirect;
       if (live && sub == 0) {
-        grad_idx[rowP] = on ? p[X] : -1;
-        grad_idx[rowN] = (on && !same) ? n[X] : -1;
+        grad_idx[rowP] = (on && !dirP) ? p[X] : -1;
+        grad_idx[rowN] = (on && !same && !dirN) ? n[X] : -1;
       }
       if (!on) continue;
       const RowCoef kp = row_coef(cp, fp, X, max_norm, neg_lr);
       const RowCoef kn = row_coef(cn, fn, X, max_norm, neg_lr);
-      float* gp = grad_val + rowP * d;
-      float* gn = grad_val + rowN * d;
+      float* gp = dirP ? table_rw + (int64_t)p[X] * d : grad_val + rowP * d;
+      float* gn = dirN ? table_rw + (int64_t)n[X] * d : grad_val + rowN * d;
 #pragma unroll
       for (int it = 0; it < NITER; ++it) {
         const int j = sub + it * LPT;
@@ -253,14 +159,20 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
         if (same) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) { pre_[v] += nre_[v]; pim_[v] += nim_[v]; }
-          store_vec<VEC>(gp + j * VEC, pre_);
-          store_vec<VEC>(gp + k + j * VEC, pim_);
         } else {
-          store_vec<VEC>(gp + j * VEC, pre_);
-          store_vec<VEC>(gp + k + j * VEC, pim_);
+          if (dirN) {   // x' = x + (-lr g): same bits as the apply kernel's 0 + g then x + sum
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { nre_[v] += xn[X].re[it][v]; nim_[v] += xn[X].im[it][v]; }
+          }
           store_vec<VEC>(gn + j * VEC, nre_);
           store_vec<VEC>(gn + k + j * VEC, nim_);
         }
+        if (dirP) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { pre_[v] += xp[X].re[it][v]; pim_[v] += xp[X].im[it][v]; }
+        }
+        store_vec<VEC>(gp + j * VEC, pre_);
+        store_vec<VEC>(gp + k + j * VEC, pim_);
       }
     }
   }
@@ -337,7 +249,7 @@ int complex_hinge_loss_launch(const float* table, int64_t N, int32_t d, const in
 int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos,
                               const int32_t* neg, int64_t B, float margin, float lr, float max_norm,
                               float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st,
-                              hipEvent_t ev_start, hipEvent_t ev_stop) {
+                              hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* slot_item) {
   Shape s;
   if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   // the gradient rows are written with the same vector width: grad_val must be as aligned as rows
@@ -346,7 +258,7 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val)
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item)
   GE_DISPATCH_SHAPE(s, 2, CALL);
 #undef CALL
   return launch_status();

@@ -18,14 +18,39 @@
 // rows with <= C occurrences (the vast majority) are bitwise reproducible.  Only rows split
 // over several work items combine their partial sums with atomics.
 #include "ge_common.h"
+#include <cstdlib>
 
 namespace ge {
 
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr);
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 
+struct FusedArgs {
+  const int32_t* slot_item; const int32_t* items; const int32_t* occ;
+  int32_t* item_cnt; int32_t* row_cnt; float* partials; int32_t* gidx; float* gval; int gstride; int debug;
+};
+bool fused_shape_ok(int d, const void* table, int& lpt, int& niter);
+int fused_gstride(int d);
+int complex_fused_step_launch(float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float,
+                              float*, const FusedArgs&, hipStream_t, hipEvent_t, hipEvent_t);
+
+static int g_fused_enabled = -1;  // -1: read GE_FUSED_STEP on first use
+int set_fused_step(int on) {
+  const int prev = g_fused_enabled;
+  g_fused_enabled = on ? 1 : 0;
+  return prev;
+}
+static bool fused_enabled() {
+  if (g_fused_enabled < 0) {
+    const char* e = getenv("GE_FUSED_STEP");
+    g_fused_enabled = (e && e[0] == '1') ? 1 : 0;   // opt-in: measured slower than the two-launch step
+  }
+  return g_fused_enabled == 1;
+}
+
+constexpr int kSlotDirect = -2;  // slot_item code: sole contributor of its row, applied by the producer
 constexpr int kPrepThreads = 1024;
 constexpr int kItemCap = 16;       // C: max gradient rows summed by one wavefront
 constexpr int kPrepChunk = 32;     // steps prepared per launch
@@ -42,23 +67,34 @@ __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_
   return ((s - n0) % per) * B;
 }
 
-// per-step int32 layout of the prepared data
-__host__ __device__ inline int64_t prep_stride(int64_t B) { return 3 * B + 4 * B + 12 * B + 64; }
+// per-step int32 layout of the prepared data:
+//   neg[3B] occ[4B] items[4B*5] n_items[64] slot_item[6B] item_cnt[4B] row_cnt[4B]
+__host__ __device__ inline int64_t prep_stride(int64_t B) { return 41 * B + 64; }
+__host__ __device__ inline int64_t off_occ(int64_t B) { return 3 * B; }
+__host__ __device__ inline int64_t off_items(int64_t B) { return 7 * B; }
+__host__ __device__ inline int64_t off_nitems(int64_t B) { return 27 * B; }
+__host__ __device__ inline int64_t off_slot_item(int64_t B) { return 27 * B + 64; }
+__host__ __device__ inline int64_t off_item_cnt(int64_t B) { return 33 * B + 64; }
+__host__ __device__ inline int64_t off_row_cnt(int64_t B) { return 37 * B + 64; }
 
 __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0,
     const int32_t* __restrict__ id_to_type, int64_t N, const int64_t* __restrict__ type_offsets,
     int32_t n_types, const int32_t* __restrict__ type_ids, uint64_t seed, uint64_t global_step0,
-    int32_t padded_size, int32_t mode, int P, int32_t* __restrict__ prep) {
+    int32_t padded_size, int32_t mode, int P, int direct, int32_t* __restrict__ prep) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   int* scan = reinterpret_cast<int*>(keys + P);  // kPrepThreads + 1 ints
   const int tid = threadIdx.x;
   const int64_t s = s0 + blockIdx.x;
   const int32_t* pos = triples + 3 * step_row(first_row, T, B, s);
   int32_t* neg = prep + (int64_t)blockIdx.x * prep_stride(B);
-  int32_t* occ = neg + 3 * B;
-  int32_t* items = occ + 4 * B;
-  int32_t* n_items = items + 12 * B;
+  int32_t* occ = neg + off_occ(B);
+  int32_t* items = neg + off_items(B);
+  int32_t* n_items = neg + off_nitems(B);
+  int32_t* slot_item = neg + off_slot_item(B);
+  int32_t* item_cnt = neg + off_item_cnt(B);   // followed by row_cnt: 8B counters zeroed here, used once
+  for (int i = tid; i < 6 * B; i += kPrepThreads) slot_item[i] = -1;
+  for (int i = tid; i < 8 * B; i += kPrepThreads) item_cnt[i] = 0;
   const uint64_t step = global_step0 + (uint64_t)s;
   const bool batch_heads = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, step) : false;
   constexpr unsigned long long kInvalid = ~0ull;
@@ -105,6 +141,12 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
   auto rowof = [&](int i) -> uint32_t { return (uint32_t)(keys[i] >> 32); };
   auto valid = [&](int i) -> bool { return keys[i] != kInvalid; };
   auto is_head = [&](int i) -> bool { return valid(i) && (i == 0 || rowof(i) != rowof(i - 1)); };
+  // a row with exactly one gradient slot in the step has one reader and one writer -- the same pair:
+  // with `direct` it is not queued as an item, its slot is tagged kSlotDirect and the producing pair
+  // updates the table row itself (no gradient-row round trip, no counter)
+  auto is_sole = [&](int i) -> bool {
+    return direct && is_head(i) && !(i + 1 < P && valid(i + 1) && rowof(i + 1) == rowof(i));
+  };
   // (a) run start of every position: block-wide max-scan of the last head position per thread chunk
   int last_head = -1;
   for (int i = base; i < base + per; ++i) if (is_head(i)) last_head = i;
@@ -124,7 +166,7 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     int rs = carry;
     for (int i = base; i < base + per; ++i) {
       if (is_head(i)) rs = i;
-      if (valid(i) && ((i - rs) % kItemCap) == 0) ++cnt;
+      if (valid(i) && ((i - rs) % kItemCap) == 0 && !is_sole(i)) ++cnt;
     }
   }
   scan[tid] = cnt;
@@ -144,13 +186,19 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     if (!valid(i)) continue;
     if (is_head(i)) rs = i;
     if (((i - rs) % kItemCap) != 0) continue;
+    if (is_sole(i)) { slot_item[(uint32_t)keys[i]] = kSlotDirect; continue; }
     const uint32_t r = rowof(i);
     int e = i + 1;
     while (e < P && (e - i) < kItemCap && valid(e) && rowof(e) == r) ++e;
-    const bool multi = (i != rs) || (e < P && valid(e) && rowof(e) == r);
-    items[3 * idx] = (int32_t)r;
-    items[3 * idx + 1] = i;
-    items[3 * idx + 2] = (e - i) | (multi ? (1 << 30) : 0);
+    const bool more = (e < P && valid(e) && rowof(e) == r);
+    const bool multi = (i != rs) || more;
+    const int ordinal = (i - rs) / kItemCap;     // items of one row are consecutive
+    items[5 * idx] = (int32_t)r;
+    items[5 * idx + 1] = i;
+    items[5 * idx + 2] = (e - i) | (multi ? (1 << 30) : 0);
+    items[5 * idx + 3] = idx - ordinal;          // the row's first item
+    if (!more) items[5 * (idx - ordinal) + 4] = ordinal + 1;  // the row's item count, kept at its first item
+    for (int j = i; j < e; ++j) slot_item[(uint32_t)keys[j]] = idx;
     ++idx;
   }
 }
@@ -169,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
   const int nwaves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
   const int n_items = n_items_ptr[0];
   for (int w = wave; w < n_items; w += nwaves) {
-    const int row = items[3 * w], start = items[3 * w + 1], cm = items[3 * w + 2];
+    const int row = items[5 * w], start = items[5 * w + 1], cm = items[5 * w + 2];
     const int cnt = cm & 0x3FFFFFFF;
     const bool multi = (cm >> 30) & 1;
     // lane o (< cnt <= kItemCap) fetches slot o and whether it is live
@@ -241,10 +289,16 @@ size_t hinge_ws_bytes(int64_t B, int32_t d) {
 
 bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= kFastMaxB && d <= 1024; }
 
+// training workspace: [gidx 6B][gval 6B x gs][partials 4B x gs][prep buffer 0][prep buffer 1],
+// gs = gradient-row stride padded to whole 128-byte lines (the fused kernel's publish unit)
+static size_t train_grad_bytes(int64_t B, int32_t d) {
+  const size_t gs = (size_t)fused_gstride(d);
+  return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + align_up_sz(sizeof(float) * 6 * (size_t)B * gs, 256) +
+         align_up_sz(sizeof(float) * 4 * (size_t)B * gs, 256);
+}
 size_t train_ws_bytes(int64_t B, int32_t d) {
-  size_t need = hinge_ws_bytes(B, d);
-  if (train_fast_ok(B, d)) need += 2 * sizeof(int32_t) * (size_t)kPrepChunk * (size_t)prep_stride(B);  // double-buffered
-  return need;
+  if (!train_fast_ok(B, d)) return hinge_ws_bytes(B, d);
+  return train_grad_bytes(B, d) + 2 * sizeof(int32_t) * (size_t)kPrepChunk * (size_t)prep_stride(B);  // double-buffered
 }
 
 static int prep_pow2(int64_t B) {
@@ -302,7 +356,11 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
   int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
   float* gval = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256));
   const bool fast = train_fast_ok(B, d) && workspace_bytes >= train_ws_bytes(B, d);
-  int32_t* prep_base = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + hinge_ws_bytes(B, d));
+  const size_t grow = (size_t)fused_gstride(d);  // floats per gradient row in the fused layout
+  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(gval) + align_up_sz(sizeof(float) * 6 * (size_t)B * grow, 256));
+  int32_t* prep_base = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + train_grad_bytes(B, d));
+  int lpt_, niter_;
+  const bool fused = fast && model == 0 && fused_enabled() && fused_shape_ok(d, table, lpt_, niter_);
   const int64_t buf_ints = (int64_t)kPrepChunk * prep_stride(B);
   const int P = prep_pow2(B);
   const size_t lds = sizeof(unsigned long long) * (size_t)P + sizeof(int) * (kPrepThreads + 1);
@@ -320,7 +378,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     int32_t* buf = prep_base + (chunk & 1) * buf_ints;
     hipLaunchKernelGGL(train_prepare_kernel, dim3((unsigned)todo), dim3(kPrepThreads), lds, aux->stream, triples, T,
                        first_row, B, s0, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
-                       padded_size, mode, P, buf);
+                       padded_size, mode, P, model == 0 ? 1 : 0, buf);
     int rc = launch_status();
     if (rc) return rc;
     GE_HIP_TRY(hipEventRecord(aux->prep_done[chunk & 1], aux->stream));
@@ -370,10 +428,23 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     // they report the kernel's own begin/end timestamps, like rocprofv3's kernel trace
     hipEvent_t g0 = ev_kernel == 1 ? e0 : nullptr, g1 = ev_kernel == 1 ? e1 : nullptr;
     hipEvent_t a0 = ev_kernel == 2 ? e0 : nullptr, a1 = ev_kernel == 2 ? e1 : nullptr;
-    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1)
+    if (fused) {
+      // one launch per step: gradients + sparse update ("last arriver executes", ge_fused.hip)
+      int32_t* sp = const_cast<int32_t*>(step_prep);
+      FusedArgs fa{sp + off_slot_item(B), sp + off_items(B), sp + off_occ(B), sp + off_item_cnt(B),
+                   sp + off_row_cnt(B), partials, gidx, gval, (int)grow, 0};
+      rc = complex_fused_step_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, fa, st, g0, g1);
+      if (rc) return rc;
+      if (a0) { (void)hipEventRecord(a0, st); (void)hipEventRecord(a1, st); }
+      if ((s % kPrepChunk) == kPrepChunk - 1 || s == n_steps - 1)
+        GE_HIP_TRY(hipEventRecord(aux->buf_free[(s / kPrepChunk) & 1], st));
+      continue;
+    }
+    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1,
+                                                fast ? step_prep + off_slot_item(B) : nullptr)
                     : hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1);
     if (rc) return rc;
-    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + 7 * B, step_prep + 19 * B, step_prep + 3 * B, gidx, gval, st, a0, a1);
+    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + off_items(B), step_prep + off_nitems(B), step_prep + off_occ(B), gidx, gval, st, a0, a1);
     else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
     if (rc) return rc;
     if (fast && ((s % kPrepChunk) == kPrepChunk - 1 || s == n_steps - 1))

@@ -146,6 +146,15 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * `stream` immediately before and after kernel `ev_kernel` of every step (0 = sampler,
  * 1 = gather+score+hinge+grad, 2 = scatter-add) -- the hook bench.py uses to time one kernel. */
 size_t ge_train_workspace_bytes(int64_t B, int32_t d);
+/* Selects how the prepared path executes a ComplEx step.  0 (default) = two launches per step:
+ * gradients (rows with a single gradient slot in the step are updated right there by the pair that
+ * owns the slot), then the row-sorted apply.  1 (opt-in, or env GE_FUSED_STEP=1) = ONE launch per
+ * step: every pair publishes its gradient rows write-through (sc1), drains, and bumps per-row
+ * arrival counters; the last arriver of a row sums and applies it ("last arriver executes": no grid
+ * barrier, no spin; bitwise-reproducible incl. hot rows, bitwise-equal to mode 0 on rows with <= 16
+ * occurrences).  Mode 1 is validated but measured slower at B=4096 (36 vs 22 us/step: the chain
+ * through the hottest rows is serial), so it is not the default.  Returns the previous setting. */
+int ge_set_fused_step(int on);
 int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T,
                    int64_t first_row, int64_t B, int64_t n_steps, const int32_t* id_to_type,
                    const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,

@@ -412,3 +412,60 @@ def test_bernoulli_sampler_bit_exact_vs_pinned_oracle(H):
     known = {tuple(x) for x in tri}
     ok = neg[:, 2] >= 0
     assert not any(tuple(int(v) for v in row) in known for row in neg[ok])
+
+
+# ---------------------------------------------------------------- fused single-launch step ("last arriver executes")
+def _set_fused(on):
+    from graphembeddings_amd import _lib
+    return _lib.load().ge_set_fused_step(int(on))
+
+
+def test_fused_step_is_bitwise_equal_to_two_kernel_path_on_uniform_ids(H):
+    """Rows with <= 16 occurrences per step are summed in the same slot order by both paths: over
+    hundreds of dependent steps any stale or torn hand-off would break bitwise equality."""
+    rng = np.random.default_rng(1)
+    N, d, B, T = 60000, 200, 4096, 200000
+    tri = np.stack([rng.integers(0, N, T), rng.integers(0, N, T), rng.integers(0, N, T)], 1).astype(np.int32)
+    tt = H.TypeTables.from_host(np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32),
+                                padded_size=0)
+    base = dev((rng.standard_normal((N, d)) * 0.08).astype(np.float32))
+    outs, losses = [], []
+    try:
+        for fused in (1, 0, 1):
+            _set_fused(fused)
+            emb = base.clone()
+            tr = H.Trainer(emb, dev(tri), tt, B, seed=5, learning_rate=0.05, decay_steps=100.0)
+            l = tr.run(300, keep_losses=True)
+            torch.cuda.synchronize()
+            outs.append(emb)
+            losses.append(l)
+    finally:
+        _set_fused(0)
+    assert torch.equal(losses[0], losses[1]) and torch.equal(outs[0], outs[1])   # fused == two-kernel
+    assert torch.equal(outs[0], outs[2])                                          # and reproducible
+
+
+def test_fused_step_with_hot_rows_is_reproducible_and_matches(H):
+    """FB15k-shaped Zipfian batch: rows with hundreds of occurrences take the two-level (partial sums,
+    fixed item order) route -> two fused runs are bitwise identical, and they agree with the
+    two-kernel path (which combines hot rows with float atomics) to fp32 reordering noise."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    tri = dev(D.synthetic_fb15k_triples(fb, n_triples=100000, seed=2))
+    base = H.init_embeddings(fb.entity_count, 200, seed=1)
+    outs = []
+    try:
+        for fused in (1, 1, 0):
+            _set_fused(fused)
+            emb = base.clone()
+            tr = H.Trainer(emb, tri, tt, 4096, seed=9, learning_rate=0.1, decay_steps=500.0)
+            tr.run(150)
+            torch.cuda.synchronize()
+            outs.append(emb)
+    finally:
+        _set_fused(0)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0] - outs[2]).abs().max().item() < 2e-5
+    assert torch.isfinite(outs[0]).all()
