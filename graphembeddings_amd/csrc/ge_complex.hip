@@ -16,6 +16,7 @@
 // identity for a trilinear form, (d s/d y_X) . x_X = s / scale_X: the backward pass through the
 // clip needs no reduction beyond the forward ones.
 #include "ge_complex_dev.h"
+#include <cstdlib>
 
 namespace ge {
 
@@ -190,6 +191,10 @@ static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
   const int nvec = k / vec;
   int lpt = 16;
   while (lpt < 64 && lpt < nvec) lpt <<= 1;
+  if (const char* e = getenv("GE_LPT")) {   // tuning override: lanes per triple (power of two >= default)
+    const int v = atoi(e);
+    if (v == 16 || v == 32 || v == 64) lpt = v;
+  }
   int niter = (nvec + lpt - 1) / lpt;
   if (niter > 2) niter = 4;
   if (niter > max_niter) return false;
@@ -210,6 +215,8 @@ static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
       case 2641: { CALL(2, 64, 1); } break;                                            \
       case 2642: { CALL(2, 64, 2); } break;                                            \
       case 4161: { CALL(4, 16, 1); } break;                                            \
+      case 4162: { CALL(4, 16, 2); } break;                                            \
+      case 4322: { CALL(4, 32, 2); } break;                                            \
       case 4321: { CALL(4, 32, 1); } break;                                            \
       case 4641: { CALL(4, 64, 1); } break;                                            \
       case 4642: { CALL(4, 64, 2); } break;                                            \
