@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="auto", choices=["auto", "fb15k", "synthetic"])
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=None,
+                    help="positives per GPU per step (default 4096 on 1 GPU = config[1]; 16384 per GPU on the sharded path)")
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--model", default="complex", choices=["complex", "hole"])
     ap.add_argument("--sharded", action="store_true", help="run the row-sharded (all-to-all) path even on 1 GPU")
@@ -232,7 +233,12 @@ def run_single(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or args.sharded:
+    sharded = args.gpus > 1 or world > 1 or args.sharded
+    if args.batch is None:
+        # config[3] names no batch size: the exchange (3 collectives per step) is latency-bound at
+        # 4096 positives per GPU, 16384 amortises it; per-GPU batch is the same for every N (weak scaling)
+        args.batch = 16384 if sharded else 4096
+    if sharded:
         from graphembeddings_amd import sharded_bench
         sharded_bench.run(args)
         return
