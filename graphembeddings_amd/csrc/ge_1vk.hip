@@ -13,6 +13,7 @@
 // wave TM x TN tiles of 32x32; k is walked in chunks of 16 complex dims (= 32 real k) staged in LDS
 // with a row stride of 33 floats so the 32 rows a half-wave reads per operand fall in 32 banks.
 #include "ge_common.h"
+#include <cstdlib>
 
 namespace ge {
 
@@ -191,6 +192,119 @@ __global__ __launch_bounds__(kBlock) void score_1vK_kernel(
     }
 }
 
+// Small problems (a few hundred 64x64 tiles, e.g. B=4096 positives x K=256 shared negatives) are
+// latency-bound in the chunked kernel: 13 load->barrier->MFMA->barrier rounds at one block per CU.
+// This variant stages the WHOLE k range once (64 x (2*KP+1) floats per operand, ~100 KiB of LDS at
+// d=200), keeps every global load of the block in flight together, and then runs the MFMAs
+// back-to-back.  Row stride 2*KP+1 is odd, so the 32 rows a half-wave reads hit 32 distinct banks.
+template <bool V4>
+__global__ __launch_bounds__(kBlock) void score_1vK_fullk_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
+    const int32_t* __restrict__ cand, int64_t K, float max_norm, int apply_sigmoid, int cand_is_head,
+    float* __restrict__ out, int KP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lda = 2 * KP + 1;
+  float* As = smem;
+  float* Bs = As + 64 * lda;
+  float* sA = Bs + 64 * lda;
+  float* sB = sA + 64;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int lrow = t >> 2, lj = t & 3;
+  const int k = d >> 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  int32_t fid = -1, rid = -1, cid = -1;
+  bool abad = false, bbad = false;
+  {
+    const int64_t r = m0 + lrow;
+    if (r < B) {
+      fid = hr[2 * r]; rid = hr[2 * r + 1];
+      abad = fid < 0 || fid >= N || rid < 0 || rid >= N;
+      if (abad) { fid = -1; rid = -1; }
+    }
+    const int64_t c = n0 + lrow;
+    if (c < K) {
+      cid = cand[c];
+      bbad = cid < 0 || cid >= N;
+      if (bbad) cid = -1;
+    }
+  }
+  float ssf = 0.f, ssr = 0.f, ssc = 0.f;
+  const float* frow = table + (int64_t)(fid >= 0 ? fid : 0) * d;
+  const float* rrow = table + (int64_t)(rid >= 0 ? rid : 0) * d;
+  const float* crow = table + (int64_t)(cid >= 0 ? cid : 0) * d;
+  float* arow = As + lrow * lda;
+  float* brow = Bs + lrow * lda;
+  for (int c0 = 4 * lj; c0 < KP; c0 += 32) {   // two 4-wide column groups per pass: 12 float4 loads in flight
+    float fre[2][4], fim[2][4], rre[2][4], rim[2][4], cre[2][4], cim[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cc = c0 + 16 * u;
+      const bool in = cc < KP;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { fre[u][q] = fim[u][q] = rre[u][q] = rim[u][q] = cre[u][q] = cim[u][q] = 0.f; }
+      if (in && fid >= 0) {
+        load4<V4>(frow, cc, k, false, fre[u]); load4<V4>(frow, cc, k, true, fim[u]);
+        load4<V4>(rrow, cc, k, false, rre[u]); load4<V4>(rrow, cc, k, true, rim[u]);
+      }
+      if (in && cid >= 0) { load4<V4>(crow, cc, k, false, cre[u]); load4<V4>(crow, cc, k, true, cim[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cc = c0 + 16 * u;
+      if (cc >= KP) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ssf += fre[u][q] * fre[u][q] + fim[u][q] * fim[u][q];
+        ssr += rre[u][q] * rre[u][q] + rim[u][q] * rim[u][q];
+        ssc += cre[u][q] * cre[u][q] + cim[u][q] * cim[u][q];
+        float qre, qim;
+        if (!cand_is_head) {
+          qre = fre[u][q] * rre[u][q] - fim[u][q] * rim[u][q];
+          qim = fre[u][q] * rim[u][q] + fim[u][q] * rre[u][q];
+        } else {
+          qre = rre[u][q] * fre[u][q] + rim[u][q] * fim[u][q];
+          qim = -(rim[u][q] * fre[u][q] - rre[u][q] * fim[u][q]);
+        }
+        arow[cc + q] = qre; arow[KP + cc + q] = qim;
+        brow[cc + q] = cre[u][q]; brow[KP + cc + q] = cim[u][q];
+      }
+    }
+  }
+  // clip scales
+  ssf += __shfl_xor(ssf, 1, kWave); ssf += __shfl_xor(ssf, 2, kWave);
+  ssr += __shfl_xor(ssr, 1, kWave); ssr += __shfl_xor(ssr, 2, kWave);
+  ssc += __shfl_xor(ssc, 1, kWave); ssc += __shfl_xor(ssc, 2, kWave);
+  if (lj == 0) {
+    const float nanv = __builtin_nanf("");
+    float i0, i1;
+    sA[lrow] = abad ? nanv : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+    sB[lrow] = bbad ? nanv : clip_scale(ssc, max_norm, i0);
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  const float* ap = As + (wm * 32 + li) * lda + lh;
+  const float* bp = Bs + (wn * 32 + li) * lda + lh;
+#pragma unroll 4
+  for (int kk = 0; kk < 2 * KP; kk += 2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk], acc, 0, 0, 0);
+  const int cl = wn * 32 + li;
+  const int64_t col = n0 + cl;
+  const float sb = sB[cl];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rl = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+    const int64_t row = m0 + rl;
+    if (row < B && col < K) {
+      const float sv = acc[q] * sA[rl] * sb;
+      out[row * K + col] = apply_sigmoid ? sigmoidf_dev(sv) : sv;
+    }
+  }
+}
+
 int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                              const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
                              int cand_is_head, float* out, hipStream_t st) {
@@ -204,6 +318,24 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
   const int64_t gy = (B + bm - 1) / bm, gx = (K + bm - 1) / bm;
   if (gy > 65535 || gx > 2147483647LL) return GE_ENOTSUP;
   dim3 grid((unsigned)gx, (unsigned)gy);
+  const int KP = (k + 3) & ~3;
+  const size_t fullk_lds = sizeof(float) * (size_t)(2 * 64 * (2 * KP + 1) + 128);
+  if (!big && fullk_lds <= 150 * 1024 && !getenv("GE_1VK_CHUNKED")) {
+    static bool attr[2] = {false, false};
+    if (!attr[v4]) {
+      hipError_t e = v4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_fullk_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                        : hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_fullk_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr[v4] = true;
+    }
+    if (v4)
+      hipLaunchKernelGGL(score_1vK_fullk_kernel<true>, grid, dim3(kBlock), fullk_lds, st, table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out, KP);
+    else
+      hipLaunchKernelGGL(score_1vK_fullk_kernel<false>, grid, dim3(kBlock), fullk_lds, st, table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out, KP);
+    return launch_status();
+  }
 #define L1VK(TM, TN, V) \
   hipLaunchKernelGGL((score_1vK_kernel<TM, TN, V>), grid, dim3(kBlock), 0, st, table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out)
   if (big) { if (v4) L1VK(2, 2, true); else L1VK(2, 2, false); }

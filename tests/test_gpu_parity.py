@@ -469,3 +469,23 @@ def test_fused_step_with_hot_rows_is_reproducible_and_matches(H):
     assert torch.equal(outs[0], outs[1])
     assert (outs[0] - outs[2]).abs().max().item() < 2e-5
     assert torch.isfinite(outs[0]).all()
+
+
+def test_score_candidates_large_tiles_path(H):
+    # >= 512 tiles of 128x128: the chunked 2x2-tiles-per-wave kernel (FB15k evaluation shape family)
+    N, d, B, K = 16296, 200, 2048, 8192
+    g = torch.Generator(device="cpu").manual_seed(2)
+    table = (torch.randn(N, d, generator=g) * 0.12).cuda()
+    table[::5] *= 9.0
+    hr = torch.stack([torch.randint(1345, N, (B,), generator=g), torch.randint(0, 1345, (B,), generator=g)], 1).int().cuda()
+    cand = torch.randperm(N - 1345, generator=g)[:K].add(1345).int().cuda()
+    for cand_is_head in (False, True):
+        out = H.score_candidates(table, hr, cand, cand_is_head=cand_is_head)
+        rows = torch.randint(0, B, (3000,), generator=g).cuda()
+        cols = torch.randint(0, K, (3000,), generator=g).cuda()
+        if cand_is_head:
+            tr = torch.stack([cand[cols], hr[rows, 0], hr[rows, 1]], 1).contiguous()
+        else:
+            tr = torch.stack([hr[rows, 0], cand[cols], hr[rows, 1]], 1).contiguous()
+        per = H.evaluate_triples(tr, table)[:, 0]
+        assert (out[rows, cols] - per).abs().max().item() < SCORE_TOL
