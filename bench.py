@@ -148,7 +148,7 @@ def run_single(args):
     if workload == "fb15k":
         fb = D.fb15k_shape()
         arrays = fb.type_arrays()
-        triples = D.synthetic_fb15k_triples(fb, n_triples=483142, seed=0)
+        triples = D.synthetic_fb15k_triples(fb, n_triples=483142, seed=0, zipf_s=float(os.environ.get("GE_BENCH_ZIPF", "1.0")))
         n_rows = fb.entity_count
         name = f"FB15k-shaped (16,296 rows, 815 types, 483,142 synthetic train triples), {args.model} d={d}, batch={B}, 1 neg/pos, fused gather+score+hinge+grad + scatter SGD"
     else:

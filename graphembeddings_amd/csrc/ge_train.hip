@@ -53,7 +53,7 @@ static bool fused_enabled() {
 constexpr int kSlotDirect = -2;  // slot_item code: sole contributor of its row, applied by the producer
 constexpr int kPrepThreads = 1024;
 constexpr int kItemCap = 16;       // C: max gradient rows summed by one wavefront
-constexpr int kPrepChunk = 32;     // steps prepared per launch
+constexpr int kPrepChunk = 32;     // steps prepared per launch (two buffers of 32 x ~1.7 MB at B=4096)
 constexpr int64_t kFastMaxB = 4096;  // 4B sort keys of 8 B must fit the CU's LDS
 
 __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_t B, int64_t s) {
@@ -68,14 +68,15 @@ __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_
 }
 
 // per-step int32 layout of the prepared data:
-//   neg[3B] occ[4B] items[4B*5] n_items[64] slot_item[6B] item_cnt[4B] row_cnt[4B]
-__host__ __device__ inline int64_t prep_stride(int64_t B) { return 41 * B + 64; }
+//   neg[3B] occ[4B] items[4B*5] n_items[64] slot_item[6B] item_cnt[4B] row_cnt[4B] islots[4B*16]
+__host__ __device__ inline int64_t prep_stride(int64_t B) { return 105 * B + 64; }
 __host__ __device__ inline int64_t off_occ(int64_t B) { return 3 * B; }
 __host__ __device__ inline int64_t off_items(int64_t B) { return 7 * B; }
 __host__ __device__ inline int64_t off_nitems(int64_t B) { return 27 * B; }
 __host__ __device__ inline int64_t off_slot_item(int64_t B) { return 27 * B + 64; }
 __host__ __device__ inline int64_t off_item_cnt(int64_t B) { return 33 * B + 64; }
 __host__ __device__ inline int64_t off_row_cnt(int64_t B) { return 37 * B + 64; }
+__host__ __device__ inline int64_t off_islots(int64_t B) { return 41 * B + 64; }
 
 __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0,
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
   int32_t* items = neg + off_items(B);
   int32_t* n_items = neg + off_nitems(B);
   int32_t* slot_item = neg + off_slot_item(B);
+  int32_t* islots = neg + off_islots(B);          // per item: its <= 16 slot ids inline (-1 padded)
   int32_t* item_cnt = neg + off_item_cnt(B);   // followed by row_cnt: 8B counters zeroed here, used once
   for (int i = tid; i < 6 * B; i += kPrepThreads) slot_item[i] = -1;
   for (int i = tid; i < 8 * B; i += kPrepThreads) item_cnt[i] = 0;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     items[5 * idx + 3] = idx - ordinal;          // the row's first item
     if (!more) items[5 * (idx - ordinal) + 4] = ordinal + 1;  // the row's item count, kept at its first item
     for (int j = i; j < e; ++j) slot_item[(uint32_t)keys[j]] = idx;
+    for (int j = 0; j < kItemCap; ++j) islots[idx * kItemCap + j] = (i + j < e) ? (int32_t)(uint32_t)keys[i + j] : -1;
     ++idx;
   }
 }
@@ -210,24 +213,28 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
 template <int NJ>
 __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     float* __restrict__ table, int d, const int32_t* __restrict__ items,
-    const int32_t* __restrict__ n_items_ptr, const int32_t* __restrict__ occ,
+    const int32_t* __restrict__ n_items_ptr, const int32_t* __restrict__ islots,
     const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
   const int n_items = n_items_ptr[0];
   for (int w = wave; w < n_items; w += nwaves) {
-    const int row = items[5 * w], start = items[5 * w + 1], cm = items[5 * w + 2];
+    // two independent loads first: the item header and its inline slot list (lane o < 16 -> slot o)
+    const int row = items[5 * w], cm = items[5 * w + 2];
+    int slot_v = (lane < kItemCap) ? islots[w * kItemCap + lane] : -1;
     const int cnt = cm & 0x3FFFFFFF;
     const bool multi = (cm >> 30) & 1;
-    // lane o (< cnt <= kItemCap) fetches slot o and whether it is live
-    int slot_v = 0;
-    bool act_v = false;
-    if (lane < cnt) {
-      slot_v = occ[start + lane];
-      act_v = slot_v >= 0 && grad_idx[slot_v] >= 0;
-      if (slot_v < 0) slot_v = 0;
+    float* dst = table + (int64_t)row * d;
+    // the table row is fetched now, under the gradient-row loads, not after them
+    float base[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + kWave * j;
+      base[j] = (!multi && c < d) ? dst[c] : 0.f;
     }
+    const bool act_v = slot_v >= 0 && grad_idx[slot_v] >= 0;   // pair was hinge-active
+    if (slot_v < 0) slot_v = 0;
     const unsigned long long live = __ballot(act_v);
     if (live == 0ull) continue;  // wave-uniform
     float acc[NJ];
@@ -257,24 +264,23 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] += on[q] ? v[q][j] : 0.f;
     }
-    float* dst = table + (int64_t)row * d;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + kWave * j;
       if (c < d) {
         if (multi) atomic_add_f32(dst + c, acc[j]);
-        else dst[c] += acc[j];
+        else dst[c] = base[j] + acc[j];
       }
     }
   }
 }
 
 static int apply_sorted_launch(float* table, int d, int64_t B, const int32_t* items, const int32_t* n_items,
-                               const int32_t* occ, const int32_t* gidx, const float* gval, hipStream_t st,
+                               const int32_t* islots, const int32_t* gidx, const float* gval, hipStream_t st,
                                hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int grid = grid_for(4 * B, kBlock / kWave);  // at most 4B items
   const int nj = (d + kWave - 1) / kWave;
-#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, items, n_items, occ, gidx, gval)
+#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, items, n_items, islots, gidx, gval)
   if (nj <= 1) LA(1); else if (nj <= 2) LA(2); else if (nj <= 4) LA(4); else if (nj <= 8) LA(8); else if (nj <= 16) LA(16);
   else return GE_ENOTSUP;
 #undef LA
@@ -444,7 +450,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
                                                 fast ? step_prep + off_slot_item(B) : nullptr)
                     : hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1);
     if (rc) return rc;
-    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + off_items(B), step_prep + off_nitems(B), step_prep + off_occ(B), gidx, gval, st, a0, a1);
+    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + off_items(B), step_prep + off_nitems(B), step_prep + off_islots(B), gidx, gval, st, a0, a1);
     else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
     if (rc) return rc;
     if (fast && ((s % kPrepChunk) == kPrepChunk - 1 || s == n_steps - 1))

@@ -239,7 +239,7 @@ def fb15k_shape(data_dir: str = PACKAGE_FB15K_DIR) -> HolEData:
     return init_data(data_dir, require_train=False)
 
 
-def synthetic_fb15k_triples(data: HolEData, n_triples: int = 483142, seed: int = 0) -> np.ndarray:
+def synthetic_fb15k_triples(data: HolEData, n_triples: int = 483142, seed: int = 0, zipf_s: float = 1.0) -> np.ndarray:
     """FB15k-shaped train triples when the real triples.txt is absent: relation ~
     empirical frequency of the valid split, head/tail Zipf(s=1.0) over the entity rows."""
     rng = np.random.default_rng(seed)
@@ -249,8 +249,8 @@ def synthetic_fb15k_triples(data: HolEData, n_triples: int = 483142, seed: int =
     else:
         freq = np.ones(R)
     rel = rng.choice(R, size=n_triples, p=freq / freq.sum())
-    head = R + _zipf_sample(rng, N - R, n_triples, 1.0)
-    tail = R + _zipf_sample(rng, N - R, n_triples, 1.0)
+    head = R + _zipf_sample(rng, N - R, n_triples, zipf_s)
+    tail = R + _zipf_sample(rng, N - R, n_triples, zipf_s)
     return np.stack([head, tail, rel], axis=1).astype(np.int32)
 
 
