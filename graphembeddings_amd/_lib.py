@@ -26,6 +26,8 @@ SYMBOLS = {
     "ge_hinge_step_workspace_bytes": (_sz, [_i64, _i32]),
     "ge_complex_hinge_step": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),
     "ge_hole_hinge_step": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),
+    "ge_logloss_step_workspace_bytes": (_sz, [_i64, _i32]),
+    "ge_complex_logloss_step": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),
     "ge_hinge_grad": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, C.c_int, _p, _p, _p, _p]),
     "ge_scatter_add_rows": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p]),
     "ge_gather_rows": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p]),

@@ -17,6 +17,9 @@ int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, 
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
 int bernoulli_corrupt_launch(const int32_t*, int64_t, const int64_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, const uint32_t*, int32_t, int32_t, int32_t, uint64_t, uint64_t, int32_t*, hipStream_t);
+int complex_logloss_grad_launch(const float*, int64_t, int32_t, const int32_t*, const float*, int64_t, float, float, float, const float*, float*, int32_t*, float*, hipStream_t);
+int table_sumsq_launch(const float*, int64_t, float*, hipStream_t);
+int table_scale_launch(float*, int64_t, float, hipStream_t);
 size_t hinge_ws_bytes(int64_t, int32_t);
 size_t train_ws_bytes(int64_t, int32_t);
 int set_fused_step(int);
@@ -172,6 +175,36 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
 }
 
 int ge_set_fused_step(int on) { return set_fused_step(on); }
+
+// workspace: [sumsq: 256 B][grad_idx: 3M int32, 256-B padded][grad_val: 3M*d fp32]
+size_t ge_logloss_step_workspace_bytes(int64_t M, int32_t d) {
+  if (M <= 0 || d <= 0) return 0;
+  return 256 + align_up(sizeof(int32_t) * 3 * (size_t)M, 256) + sizeof(float) * 3 * (size_t)M * (size_t)d;
+}
+
+int ge_complex_logloss_step(float* table, int64_t N, int32_t d, const int32_t* triples, const float* labels,
+                            int64_t M, float lr, float l2, float max_norm, float* loss, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (M < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (M == 0) return 0;
+  if (!triples || !labels || !loss || !workspace) return GE_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
+  if (workspace_bytes < ge_logloss_step_workspace_bytes(M, d)) return GE_ENOMEM;
+  hipStream_t st = (hipStream_t)stream;
+  float* sumsq = reinterpret_cast<float*>(workspace);
+  int32_t* gidx = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + 256);
+  float* gval = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 256 + align_up(sizeof(int32_t) * 3 * (size_t)M, 256));
+  int rc = table_sumsq_launch(table, N * (int64_t)d, sumsq, st);                 // l2_loss of the OLD table
+  if (rc) return rc;
+  rc = complex_logloss_grad_launch(table, N, d, triples, labels, M, lr, max_norm, l2, sumsq, loss, gidx, gval, st);
+  if (rc) return rc;
+  // new = old - lr * (sparse + M * l2 * old) = old * (1 - lr*M*l2) + (-lr * sparse)
+  if (l2 != 0.f) {
+    rc = table_scale_launch(table, N * (int64_t)d, 1.0f - lr * (float)M * l2, st);
+    if (rc) return rc;
+  }
+  return scatter_add_rows_launch(table, N, d, gidx, gval, 3 * M, st);
+}
 
 int ge_event_create(void** ev) {
   if (!ev) return GE_EINVAL;

@@ -179,6 +179,91 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
   }
 }
 
+// ---------------------------------------------------------------- logistic loss (--log_loss)
+// holE.py:194-196 with labels +1 / -1 (holE.py:209, 215): per triple
+//     loss = log(1 + exp(-y s)) + l2 * l2_loss(table),   d loss/d s = -y sigma(-y s).
+// One group per triple; emits 3 IndexedSlices rows (h, t, r) already multiplied by -lr.  The dense
+// L2 term is handled by the caller (a whole-table scale, see ge_complex_logloss_step).
+template <int VEC, int LPT, int NITER>
+__global__ __launch_bounds__(kBlock) void complex_logloss_grad_kernel(
+    const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ triples,
+    const float* __restrict__ labels, int64_t M, float lr, float max_norm, float l2,
+    const float* __restrict__ table_sumsq, float* __restrict__ loss, int32_t* __restrict__ grad_idx,
+    float* __restrict__ grad_val) {
+  constexpr int GPW = kWave / LPT;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int k = d >> 1, nvec = k / VEC;
+  const float neg_lr = -lr;
+  const float reg = l2 * 0.5f * table_sumsq[0];   // l2 * tf.nn.l2_loss(embeddings), same for every row
+  for (int64_t base = wave * GPW; base < M; base += nwaves * GPW) {
+    const int64_t g = base + grp;
+    const bool live = g < M;
+    int32_t p[3] = {0, 0, 0};
+    float y = 1.f;
+    if (live) { p[0] = triples[3 * g]; p[1] = triples[3 * g + 1]; p[2] = triples[3 * g + 2]; y = labels[g]; }
+    const bool bad = bad3(N, p[0], p[1], p[2]);
+    if (bad) { p[0] = p[1] = p[2] = 0; }
+    Row<VEC, NITER> x[3];
+#pragma unroll
+    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, x[X]);
+    const SideFwd f = side_forward<VEC, LPT, NITER>(x[0], x[1], x[2], max_norm);
+    const float z = -y * f.s;                                            // holE.py:195
+    const float softplus = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
+    const float coef = -y * sigmoidf_dev(z);                             // d/ds log(1+exp(-y s))
+    if (live && sub == 0) loss[g] = bad ? __builtin_nanf("") : softplus + reg;
+#pragma unroll
+    for (int X = 0; X < 3; ++X) {
+      const int64_t slot = g * 3 + X;
+      if (live && sub == 0) grad_idx[slot] = bad ? -1 : p[X];
+      if (!live || bad) continue;
+      const RowCoef kc = row_coef(coef, f, X, max_norm, neg_lr);
+      float* gp = grad_val + slot * d;
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        const int j = sub + it * LPT;
+        if (j >= nvec) continue;
+        float re_[VEC], im_[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float gre, gim;
+          graw<VEC, NITER>(X, x[0], x[1], x[2], it, v, gre, gim);
+          re_[v] = kc.alpha * gre + kc.beta * x[X].re[it][v];
+          im_[v] = kc.alpha * gim + kc.beta * x[X].im[it][v];
+        }
+        store_vec<VEC>(gp + j * VEC, re_);
+        store_vec<VEC>(gp + k + j * VEC, im_);
+      }
+    }
+  }
+}
+
+// sum of squares of the whole table (tf.nn.l2_loss * 2) -> out[0]; out must be zeroed before.
+__global__ __launch_bounds__(kBlock) void table_sumsq_kernel(const float* __restrict__ t, int64_t n,
+                                                              float* __restrict__ out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = t[i];
+    acc += v * v;
+  }
+  acc = group_sum<kWave>(acc);
+  __shared__ float part[kBlock / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) s += part[w];
+    atomic_add_f32(out, s);
+  }
+}
+
+// table *= factor : the dense part of the SGD step, (1 - lr * M * l2)
+__global__ __launch_bounds__(kBlock) void table_scale_kernel(float* __restrict__ t, int64_t n, float factor) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    t[i] *= factor;
+}
+
 // ---------------------------------------------------------------- dispatch
 struct Shape { int vec, lpt, niter; };
 
@@ -268,6 +353,35 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item)
   GE_DISPATCH_SHAPE(s, 2, CALL);
 #undef CALL
+  return launch_status();
+}
+
+int complex_logloss_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* triples,
+                                const float* labels, int64_t M, float lr, float max_norm, float l2,
+                                const float* table_sumsq, float* loss, int32_t* grad_idx, float* grad_val,
+                                hipStream_t st) {
+  Shape s;
+  if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
+  if ((reinterpret_cast<uintptr_t>(grad_val) % (s.vec * 4)) != 0) return GE_EINVAL;
+  if (M == 0) return 0;
+  const int gpb = (kBlock / kWave) * (kWave / s.lpt);
+  const int grid = grid_for(M, gpb);
+#define CALL(V, L, NI) \
+  hipLaunchKernelGGL((complex_logloss_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, rows, N, d, triples, labels, M, lr, max_norm, l2, table_sumsq, loss, grad_idx, grad_val)
+  GE_DISPATCH_SHAPE(s, 2, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int table_sumsq_launch(const float* table, int64_t n, float* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(table_sumsq_kernel, dim3(grid_for(n, kBlock * 8)), dim3(kBlock), 0, st, table, n, out);
+  return launch_status();
+}
+
+int table_scale_launch(float* table, int64_t n, float factor, hipStream_t st) {
+  hipLaunchKernelGGL(table_scale_kernel, dim3(grid_for(n, kBlock * 8)), dim3(kBlock), 0, st, table, n, factor);
   return launch_status();
 }
 

@@ -189,6 +189,38 @@ class HingeSGD:
         return loss.view(-1, 1)
 
 
+class LogLossSGD:
+    """The --log_loss branch (holE.py:194-196, 206-220): logistic loss over the positives (label +1)
+    and `negative_ratio` corrupted batches (label -1) plus l2_regularization * l2_loss(whole table),
+    minimised by plain SGD on the SUM of the loss vector (holE.py:296)."""
+
+    def __init__(self, embeddings: torch.Tensor, l2_regularization: float = 0.1, max_norm: float = 1.0):
+        self.embeddings = _table(embeddings)
+        self.l2, self.max_norm = float(l2_regularization), float(max_norm)
+        self._ws = None
+
+    def step(self, pos: torch.Tensor, negs, lr: float) -> torch.Tensor:
+        """pos [B,3]; negs: [K,B,3] tensor or list of K [B,3] tensors.  Returns the loss vector
+        [(1+K)*B, 1] in the reference's concat order (holE.py:220)."""
+        emb = self.embeddings
+        p = _triples(pos, "pos")
+        if isinstance(negs, (list, tuple)):
+            negs = torch.stack([_triples(n, "neg") for n in negs], 0)
+        negs = negs.to(torch.int32).reshape(-1, 3)
+        tri = torch.cat([p, negs], 0).contiguous()
+        M, B = tri.shape[0], p.shape[0]
+        labels = torch.ones(M, dtype=torch.float32, device=emb.device)
+        labels[B:] = -1.0
+        need = _lib.load().ge_logloss_step_workspace_bytes(M, emb.shape[1])
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=emb.device)
+        loss = torch.empty(M, dtype=torch.float32, device=emb.device)
+        _lib.call("ge_complex_logloss_step", emb.data_ptr(), emb.shape[0], emb.shape[1], tri.data_ptr(),
+                  labels.data_ptr(), M, float(lr), self.l2, self.max_norm, loss.data_ptr(), self._ws.data_ptr(),
+                  self._ws.numel(), _stream())
+        return loss.view(-1, 1)
+
+
 def hinge_grad(rows: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, lr: float, *, margin=0.2,
                model="complex", max_norm=1.0):
     """First half of the step (ge_hinge_grad): returns (loss [B], grad_idx [6B] int32, grad_val [6B,d])

@@ -75,8 +75,8 @@ def load_checkpoint(output_dir: str, device='cuda'):
 
 
 def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
-    if FLAGS.log_loss:
-        raise NotImplementedError('--log_loss (holE.py:194-196, 206-220) is outside the hinge hot path')
+    if FLAGS.log_loss and FLAGS.model != 'complex':
+        raise NotImplementedError('--log_loss is implemented for the ComplEx score (holE.py:191-196)')
     batch_count = data.triple_count // FLAGS.batch_size
     log('Embedding dimension: ', FLAGS.embedding_dim, 'Batch size: ', FLAGS.batch_size, 'Batch count: ', batch_count)
     if batch_count < 2:
@@ -107,6 +107,28 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
     valid = None
     if data.validation_triples is not None and len(data.validation_triples) >= FLAGS.batch_size:
         valid = torch.as_tensor(data.validation_triples).cuda()
+    logloss = H.LogLossSGD(embeddings, FLAGS.l2_regularization) if FLAGS.log_loss else None
+    K = max(1, FLAGS.negative_ratio)
+
+    def logloss_steps(n, lr_zero=False, batch_override=None):
+        """--log_loss branch (holE.py:206-220): K corrupted batches per step, label -1; Python per step."""
+        out = None
+        for _ in range(n):
+            if batch_override is None:
+                if trainer.row + FLAGS.batch_size > trainer.triples.shape[0]:
+                    trainer.row = 0
+                pos = trainer.triples[trainer.row:trainer.row + FLAGS.batch_size]
+            else:
+                pos = batch_override
+            gs = trainer.global_step
+            negs = [H.corrupt_batch(tt, data.relation_count, pos, seed=FLAGS.seed, step=gs * K + i) for i in range(K)]
+            out = logloss.step(pos, negs, 0.0 if lr_zero else trainer.learning_rate(gs))
+            if batch_override is None:
+                trainer.row += FLAGS.batch_size
+                trainer.global_step += 1
+                trainer.last_loss = out[:, 0]
+        return out
+
     tick = max(1, batch_count // 16)          # guard for the ZeroDivisionError of holE.py:351
     pocket_loss = 2.
     history = []
@@ -119,9 +141,12 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
         while batch < batch_count and not done:
             if batch % tick == 0 and valid is not None:
                 sel = torch.randint(0, valid.shape[0], (FLAGS.batch_size,), device='cuda', generator=gen)
-                vlm = float(H.evaluate_batch(valid[sel], embeddings, tt, None, data.relation_count,
-                                             margin=FLAGS.margin, model=FLAGS.model, seed=FLAGS.seed ^ 0x5EED,
-                                             step=trainer.global_step).mean())
+                if logloss is not None:   # mean of the loss vector at lr = 0 (table untouched)
+                    vlm = float(logloss_steps(1, lr_zero=True, batch_override=valid[sel].contiguous()).mean())
+                else:
+                    vlm = float(H.evaluate_batch(valid[sel], embeddings, tt, None, data.relation_count,
+                                                 margin=FLAGS.margin, model=FLAGS.model, seed=FLAGS.seed ^ 0x5EED,
+                                                 step=trainer.global_step).mean())
                 log('\tStep {} Validation Loss: {}...'.format(trainer.global_step, vlm))
                 history.append((trainer.global_step, vlm))
                 if vlm < pocket_loss:
@@ -134,7 +159,10 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
             if FLAGS.max_steps:
                 n = min(n, FLAGS.max_steps - (trainer.global_step - global_step))
             if n > 0:
-                trainer.run(n)
+                if logloss is not None:
+                    logloss_steps(n)
+                else:
+                    trainer.run(n)
             batch += max(n, 0)
             if FLAGS.max_steps and trainer.global_step - global_step >= FLAGS.max_steps:
                 done = True

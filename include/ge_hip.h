@@ -76,6 +76,17 @@ int ge_hole_hinge_step(float* table, int64_t N, int32_t d, const int32_t* pos, c
                        int64_t B, float margin, float lr, float max_norm, float* loss,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* --- the --log_loss branch (holE.py:194-196, 206-220 + minimize, holE.py:296), ComplEx: `triples`
+ * [M,3] is the concatenation of the B positives and negative_ratio corrupted batches, `labels` [M]
+ * fp32 +1 / -1 (holE.py:209, 215).  loss[i] = log(1 + exp(-y_i s_i)) + l2 * sum(table^2)/2
+ * (tf.nn.l2_loss of the WHOLE table, holE.py:196).  minimize() differentiates the SUM of the loss
+ * vector, so the dense term counts once per row: table <- table*(1 - lr*M*l2) - lr * sparse grads.
+ * workspace >= ge_logloss_step_workspace_bytes(M, d), 256-B aligned. */
+size_t ge_logloss_step_workspace_bytes(int64_t M, int32_t d);
+int ge_complex_logloss_step(float* table, int64_t N, int32_t d, const int32_t* triples, const float* labels,
+                            int64_t M, float lr, float l2, float max_norm, float* loss, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* --- the two halves of the step, exposed for the row-sharded multi-GPU path (rows are fetched
  * from / gradients routed to their owner GPU between the halves).
  * ge_hinge_grad: `rows` is any [N,d] row store (the table itself, or a staging buffer of fetched

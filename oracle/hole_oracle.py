@@ -423,3 +423,37 @@ def reference_padded_resample(type_lists, padded_size, rng):
     """The per-batch host loop of holE.py:343-344 verbatim in behaviour:
     for every type, padded_size random.choice() draws with replacement."""
     return np.array([[rng.choice(v) for _ in range(padded_size)] for v in type_lists])
+
+
+# --------------------------------------------------------------------------
+# f2. logistic-loss mode  (holE.py:194-196, 206-220; flags --log_loss --negative_ratio --l2_regularization)
+# --------------------------------------------------------------------------
+
+def logloss_values(triples, labels, table, l2: float, max_norm: float = 1.0) -> np.ndarray:
+    """holE.py:195-196 per triple:  log(1 + exp(-label * score)) + l2 * tf.nn.l2_loss(embeddings),
+    l2_loss = sum(table**2)/2 over the WHOLE table (added to every row of the loss vector)."""
+    s = complex_score(triples, table, max_norm)
+    y = np.asarray(labels, dtype=table.dtype)
+    return np.log1p(np.exp(-y * s)) + l2 * 0.5 * np.sum(table * table)
+
+
+def logloss_step(table, pos, negs, lr: float, l2: float, max_norm: float = 1.0):
+    """One step of the --log_loss branch (holE.py:206-220 then minimize, holE.py:296): the loss
+    vector is concat(positives with label +1, negative_ratio corrupted batches with label -1);
+    minimize() differentiates its SUM, so the dense L2 term is counted once per loss row:
+        grad = sum_i (-y_i sigma(-y_i s_i)) ds_i/dtable  +  M * l2 * table,   M = (1+K) * B
+        new  = table - lr * grad.
+    negs: [K,B,3].  Returns (new_table, loss [M])."""
+    pos = np.asarray(pos)
+    negs = np.asarray(negs).reshape(-1, pos.shape[0], 3)
+    triples = np.concatenate([pos] + [n for n in negs], 0)
+    labels = np.concatenate([np.ones(len(pos)), -np.ones(len(triples) - len(pos))]).astype(table.dtype)
+    loss = logloss_values(triples, labels, table, l2, max_norm)
+    s = complex_score(triples, table, max_norm)
+    coef = -labels * sigmoid(-labels * s)
+    gh, gt, gr = _side_grads(triples, table, coef, max_norm, "complex")
+    new = table * (1.0 - lr * len(triples) * l2)
+    np.subtract.at(new, triples[:, 0], lr * gh)
+    np.subtract.at(new, triples[:, 1], lr * gt)
+    np.subtract.at(new, triples[:, 2], lr * gr)
+    return new, loss

@@ -489,3 +489,27 @@ def test_score_candidates_large_tiles_path(H):
             tr = torch.stack([hr[rows, 0], cand[cols], hr[rows, 1]], 1).contiguous()
         per = H.evaluate_triples(tr, table)[:, 0]
         assert (out[rows, cols] - per).abs().max().item() < SCORE_TOL
+
+
+# ---------------------------------------------------------------- f2: --log_loss branch
+@pytest.mark.parametrize("d,K", [(200, 1), (128, 3), (50, 2)])
+def test_logloss_step_matches_oracle(H, G, d, K):
+    table = G[f"d{d}_table"]
+    pos = G[f"d{d}_pos"]
+    rng = np.random.default_rng(K)
+    negs = np.stack([pos.copy() for _ in range(K)])
+    for kk in range(K):
+        negs[kk, :, kk % 2] = rng.integers(8, table.shape[0], len(pos))
+    lr, l2 = 0.01, 0.003
+    emb = dev(table).clone()
+    opt = H.LogLossSGD(emb, l2_regularization=l2)
+    loss = opt.step(dev(pos), dev(negs), lr).cpu().numpy()[:, 0]
+    new, oloss = O.logloss_step(table.astype(np.float64), pos, negs, lr, l2)
+    assert loss.shape == ((1 + K) * len(pos),)
+    assert np.abs(loss - oloss).max() < 2e-5 * max(1.0, np.abs(oloss).max())
+    assert np.abs(emb.cpu().numpy() - new).max() < TABLE_TOL
+    # lr = 0 leaves the table bit-identical (used for the validation loss)
+    before = emb.clone()
+    opt.step(dev(pos), dev(negs), 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(emb, before)

@@ -142,3 +142,22 @@ def test_fb15k_scale_ranks_match_oracle_on_real_id_files():
         assert [raw[i]] == rp and [fil[i]] == fp
     m = E.score_mrr(raw, fil, verbose=False)
     assert 0 < m["filtered_mrr"] <= 1 and m["filtered_mrr"] >= m["raw_mrr"]
+
+
+def test_log_loss_driver_runs(tmp_path):
+    """--log_loss --negative_ratio 2 with a small l2: the loop of holE.py:206-220 end to end."""
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import train as T
+    dd = tmp_path / "data"
+    dd.mkdir()
+    data_dir = _toy_kg(dd)
+    out = str(tmp_path / "run_ll")
+    argv = ["--data_dir", data_dir, "--output_dir", out, "--batch_size", "64", "--embedding_dim", "32",
+            "--num_epochs", "40", "--learning_rate", "0.05", "--log_loss", "--negative_ratio", "2",
+            "--l2_regularization", "1e-5", "--padded_size", "64", "--seed", "1"]
+    FLAGS = T.build_parser().parse_args(argv)
+    data = D.init_data(data_dir)
+    res = T.run_training(data, FLAGS, log=lambda *a: None)
+    assert res["steps"] == 40 * (data.triple_count // 64 - 1)
+    assert np.isfinite(res["final_mean_hinge"]) and res["final_mean_hinge"] < np.log(2.0) + 0.05
+    assert res["pocket_loss"] < 0.69      # below log(2): the model separates positives from negatives

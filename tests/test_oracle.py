@@ -237,3 +237,34 @@ def test_eval_link_prediction_toy():
     assert m["raw_mrr"] == pytest.approx((1 / 3 + 1 / 6) / 2)
     assert m["filtered_mrr"] == pytest.approx((1 / 2 + 1 / 5) / 2)
     assert m["hits1"] == 0 and m["hits3"] == 50 and m["hits10"] == 100
+
+
+# ---------------------------------------------------------------- f2: logistic-loss mode
+def test_logloss_step_matches_torch_autograd(G):
+    d = 128
+    table = G[f"d{d}_table"].astype(np.float64)
+    pos = G[f"d{d}_pos"]
+    keep = ~np.isin(pos, [0, 1]).any(axis=1)
+    pos = pos[keep]
+    rng = np.random.default_rng(0)
+    negs = np.stack([pos.copy() for _ in range(3)])
+    for kk in range(3):
+        negs[kk, :, kk % 2] = rng.integers(8, 64, len(pos))
+    negs[(negs == 0) | (negs == 1)] = 9
+    lr, l2 = 0.01, 0.003
+    new, loss = O.logloss_step(table, pos, negs, lr, l2)
+    emb = torch.tensor(table, dtype=torch.float64, requires_grad=True)
+
+    def lookup(ids):
+        t = emb[torch.as_tensor(ids, dtype=torch.long)]
+        return t * torch.minimum(torch.rsqrt((t * t).sum(1, keepdim=True)), torch.ones(1, dtype=torch.float64))
+    tri = np.concatenate([pos] + list(negs), 0)
+    y = torch.tensor(np.concatenate([np.ones(len(pos)), -np.ones(3 * len(pos))]))
+    h, t, r = lookup(tri[:, 0]), lookup(tri[:, 1]), lookup(tri[:, 2])
+    k = d // 2
+    hc, tc, rc = (torch.complex(v[:, :k], v[:, k:]) for v in (h, t, r))
+    s = (hc * (rc * torch.conj(tc))).real.sum(1)
+    lvec = torch.log(1.0 + torch.exp(-y * s)) + l2 * 0.5 * (emb * emb).sum()     # holE.py:195-196
+    lvec.sum().backward()
+    assert np.abs(loss - lvec.detach().numpy()).max() < 1e-10
+    assert np.abs(new - (emb.detach() - lr * emb.grad).numpy()).max() < 1e-12
