@@ -111,7 +111,11 @@ def cpu_baseline_fb15k(fb, type_arrays, d, B, seconds):
     from oracle import hole_oracle as O
     from graphembeddings_amd import data as D
     names, id_to_type, offsets, ids = type_arrays
-    threads = min(CO.num_threads(), os.cpu_count() or 1)
+    try:
+        avail = len(os.sched_getaffinity(0))      # the cores this process may actually run on
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(CO.num_threads(), avail))
     table = O.init_table(fb.entity_count, d, seed=0)
     tri = D.synthetic_fb15k_triples(fb, n_triples=max(4 * B, 20000), seed=0)
     nb = len(tri) // B
@@ -240,7 +244,15 @@ def main():
         args.batch = 16384 if sharded else 4096
     if sharded:
         from graphembeddings_amd import sharded_bench
-        sharded_bench.run(args)
+        try:
+            sharded_bench.run(args)
+        except Exception as e:  # leave a diagnosable line for the driver, then fail loudly
+            import traceback
+            traceback.print_exc()
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(json.dumps({"metric": "scored triples/sec/GPU (d=200)", "value": 0.0, "unit": "scored triples/s",
+                                  "n_gpus": world, "error": f"{type(e).__name__}: {e}"}), flush=True)
+            sys.exit(1)
         return
     run_single(args)
 
