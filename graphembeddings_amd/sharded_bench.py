@@ -24,10 +24,17 @@ def run(args):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # rehearsal knobs (one-GPU boxes): GE_DIST_BACKEND=gloo GE_SINGLE_DEVICE=1 run every rank on cuda:0
+    backend = os.environ.get("GE_DIST_BACKEND", "nccl")
+    if os.environ.get("GE_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     d, B, K, W = args.dim, args.batch, args.steps, args.warmup
     n_rel, n_ent = 18, args.entities
     N = n_rel + n_ent
