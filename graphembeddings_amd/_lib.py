@@ -30,6 +30,7 @@ SYMBOLS = {
     "ge_complex_logloss_step": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),
     "ge_hinge_grad": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, C.c_int, _p, _p, _p, _p]),
     "ge_scatter_add_rows": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p]),
+    "ge_segment_sum_rows": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p]),
     "ge_gather_rows": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p]),
     "ge_corrupt_batch": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _u64, _u64, _i32, _i32, _p, _p]),
     "ge_bernoulli_corrupt_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _u64, _u64, _p, _p]),

@@ -13,6 +13,7 @@ int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int hole_max_dim();
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
+int segment_sum_rows_launch(const float*, int64_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t, float*, int64_t, int, hipStream_t);
 int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float*, hipStream_t);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
@@ -77,6 +78,15 @@ int ge_scatter_add_rows(float* table, int64_t N, int32_t d, const int32_t* idx, 
   if (R < 0 || !ok_table(table, N, d)) return GE_EINVAL;
   if (R > 0 && (!idx || !val)) return GE_EINVAL;
   return scatter_add_rows_launch(table, N, d, idx, val, R, (hipStream_t)stream);
+}
+
+int ge_segment_sum_rows(const float* src, int64_t src_rows, const int32_t* src_idx, const int32_t* order,
+                        const int32_t* begin, const int32_t* len, const int32_t* target, int64_t n_items,
+                        int32_t d, float* out, int64_t out_rows, int32_t accumulate, void* stream) {
+  if (n_items < 0 || src_rows < 0 || !ok_table(out, out_rows, d) || (accumulate != 0 && accumulate != 1)) return GE_EINVAL;
+  if (n_items > 0 && (!src || !order || !begin || !len || !target)) return GE_EINVAL;
+  return segment_sum_rows_launch(src, src_rows, src_idx, order, begin, len, target, n_items, d, out, out_rows,
+                                 accumulate, (hipStream_t)stream);
 }
 
 int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx, int64_t R, float* out,

@@ -248,6 +248,32 @@ def scatter_add_rows(table: torch.Tensor, idx: torch.Tensor, val: torch.Tensor) 
               val.data_ptr(), idx.numel(), _stream())
 
 
+def segment_sum_rows(src: torch.Tensor, src_idx, order: torch.Tensor, begin: torch.Tensor, length: torch.Tensor,
+                     target: torch.Tensor, out: torch.Tensor, accumulate: bool) -> None:
+    """Planned, atomic-free scatter (ge_segment_sum_rows): item i sums src[order[begin[i]:begin[i]+length[i]]]
+    into out[target[i]] (plain store / RMW), or atomically into out[~target[i]] when target[i] < 0."""
+    out = _table(out)
+    for name, t in (("src", src), ("order", order), ("begin", begin), ("length", length), ("target", target)):
+        _need_cuda(t, name)
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+    if src.dtype != torch.float32 or src.dim() != 2 or src.shape[1] != out.shape[1]:
+        raise ValueError("src must be fp32 [rows, embedding_dim]")
+    if any(t.dtype != torch.int32 for t in (order, begin, length, target)):
+        raise ValueError("order/begin/length/target must be int32")
+    if not (begin.numel() == length.numel() == target.numel()):
+        raise ValueError("begin, length, target must have one entry per item")
+    sidx = 0
+    if src_idx is not None:
+        _need_cuda(src_idx, "src_idx")
+        if src_idx.dtype != torch.int32 or src_idx.numel() != src.shape[0] or not src_idx.is_contiguous():
+            raise ValueError("src_idx must be contiguous int32 [rows]")
+        sidx = src_idx.data_ptr()
+    _lib.call("ge_segment_sum_rows", src.data_ptr(), src.shape[0], sidx, order.data_ptr(), begin.data_ptr(),
+              length.data_ptr(), target.data_ptr(), target.numel(), out.shape[1], out.data_ptr(), out.shape[0],
+              int(bool(accumulate)), _stream())
+
+
 def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """out[i] = table[idx[i]] (zeros where idx[i] < 0)."""
     table = _table(table)

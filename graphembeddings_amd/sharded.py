@@ -16,9 +16,10 @@ units); type tables are replicated (small).  Per step each rank
      (all_to_all_single, <= 4*B_loc*d*4 bytes per rank, spread over all 7 xGMI peers at once),
   4. runs the fused gather->score->hinge->grad kernel on the staged rows (ge_hinge_grad with pos/neg
      re-indexed into the staging buffer) and pre-reduces the IndexedSlices per staged row
-     (ge_scatter_add_rows into a zeroed staging-shaped buffer),
+     (ge_segment_sum_rows: which slots feed which staged row is part of the plan, so the sum is a
+     segmented reduction without atomics; only rows with > 32 slots are split and combined atomically),
   5. returns the per-row gradient sums to the owners (all_to_all_single, the reverse of 3), which
-     apply them to their shard (ge_scatter_add_rows).
+     apply them to their shard (ge_segment_sum_rows again: one read-modify-write per distinct row).
 xGMI is point-to-point: the all-to-all drives all peer links concurrently, which is why the table
 is never all-reduced.  The only other collective is the optional scalar loss all-reduce for logging.
 
@@ -53,6 +54,9 @@ class HipKernels:
     def scatter_add_rows(self, table, idx, val):
         self.h.scatter_add_rows(table, idx, val)
 
+    def segment_sum_rows(self, src, src_idx, order, begin, length, target, out, accumulate):
+        self.h.segment_sum_rows(src, src_idx, order, begin, length, target, out, accumulate)
+
 
 def shard_rows(table: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """This rank's rows of a full table under owner(id) = id % world, local = id // world."""
@@ -64,6 +68,61 @@ def shard_num_rows(n_rows: int, rank: int, world: int) -> int:
 
 
 @dataclass
+class SegmentItems:
+    """Work items of ge_segment_sum_rows for a whole chunk; step s owns items item_start[s]:item_start[s+1]."""
+    order: torch.Tensor     # int32: source row (step-local) per sorted element, chunk-wide
+    begin: torch.Tensor     # int32 [items]: offset into `order`
+    length: torch.Tensor    # int32 [items]
+    target: torch.Tensor    # int32 [items]: destination row, or ~row when the row is split over items
+    item_start: list        # [S+1] host
+    split_rows: torch.Tensor  # int64: destination rows that are split (to be zeroed in overwrite mode)
+    split_start: list       # [S+1] host
+
+
+MAX_ITEM = 32   # source rows per work item; longer segments are split and combined atomically
+
+
+def segment_items(cnt: torch.Tensor, seg_bounds: torch.Tensor, seg_row: torch.Tensor, order: torch.Tensor) -> SegmentItems:
+    """Cut segments (cnt[i] consecutive elements of `order` each, ordered by step) into work items of
+    <= MAX_ITEM elements.  seg_bounds [S+1]: index of each step's first segment (and the total);
+    seg_row: destination row per segment.  One host sync (the per-step item ranges)."""
+    dev = cnt.device
+    n_seg = int(cnt.numel())
+    n_it = (cnt + MAX_ITEM - 1) // MAX_ITEM
+    split = n_it > 1
+    cum_it = torch.cumsum(n_it, 0)
+    cum_sp = torch.cumsum(split.to(torch.int64), 0)
+    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+    host = torch.stack([torch.cat([zero, cum_it])[seg_bounds], torch.cat([zero, cum_sp])[seg_bounds]]).cpu()
+    n_items, n_split = int(host[0, -1]), int(host[1, -1])
+    seg_off = torch.cumsum(cnt, 0) - cnt
+    item_seg = torch.repeat_interleave(torch.arange(n_seg, device=dev), n_it, output_size=n_items)
+    r = torch.arange(n_items, device=dev) - (cum_it - n_it)[item_seg]
+    begin = seg_off[item_seg] + r * MAX_ITEM
+    length = torch.clamp(cnt[item_seg] - r * MAX_ITEM, max=MAX_ITEM)
+    row = seg_row[item_seg]
+    target = torch.where(split[item_seg], -row - 1, row)
+    split_rows = seg_row[split] if n_split else torch.empty(0, dtype=torch.int64, device=dev)
+    return SegmentItems(order=order.to(torch.int32).contiguous(), begin=begin.to(torch.int32),
+                        length=length.to(torch.int32), target=target.to(torch.int32),
+                        item_start=host[0].tolist(), split_rows=split_rows, split_start=host[1].tolist())
+
+
+def _regroup(n: int, counts_src_major: torch.Tensor) -> torch.Tensor:
+    """Elements are grouped as segments (a, b) in a-major order with lengths counts_src_major[a, b];
+    returns, per element, its position when the same segments are laid out b-major (a segmented
+    transpose by index arithmetic -- no sort)."""
+    dev = counts_src_major.device
+    A, Bn = counts_src_major.shape
+    flat = counts_src_major.reshape(-1)
+    src_start = torch.cumsum(flat, 0) - flat
+    tflat = counts_src_major.t().reshape(-1)
+    dst_start = (torch.cumsum(tflat, 0) - tflat).view(Bn, A).t().reshape(-1)   # indexed by a*Bn + b
+    seg = torch.repeat_interleave(torch.arange(A * Bn, device=dev), flat, output_size=n)
+    return dst_start[seg] + (torch.arange(n, device=dev) - src_start[seg])
+
+
+@dataclass
 class ChunkPlan:
     S: int
     B: int
@@ -72,6 +131,8 @@ class ChunkPlan:
     remap: torch.Tensor     # [S,2B,3] triples re-indexed into the step's staging buffer (-1 invalid)
     req_all: torch.Tensor   # local row indices peers asked of me, ordered (step, peer)
     req_start: list
+    reduce_items: SegmentItems = None   # gradient slots -> staged rows (pre-reduction)
+    apply_items: SegmentItems = None    # received gradient sums -> shard rows (owner apply)
     unique_rows: int = 0
     remote_rows: int = 0
 
@@ -119,47 +180,79 @@ class ShardedTrainer:
     # at once: one dedup (torch.unique over step-tagged keys), one all-to-all of counts, one host
     # sync for the split sizes and one all-to-all of id lists per CHUNK instead of per step.
     def plan_chunk(self, pos: torch.Tensor, neg: torch.Tensor) -> "ChunkPlan":
-        """pos, neg: [S,B,3] int32 (this rank's positives / negatives for S consecutive steps)."""
+        """pos, neg: [S,B,3] int32 (this rank's positives / negatives for S consecutive steps).
+        One sort of the S*6B step-tagged ids gives everything: the staging order (step, owner, id),
+        the re-indexed triples, the per-owner request counts and the slot lists per staged row."""
         G, N, dev = self.world, self.N, pos.device
         S, B = int(pos.shape[0]), int(pos.shape[1])
-        ids = torch.cat([pos, neg], 1).reshape(S, 6 * B).to(torch.int64)
+        M6 = 6 * B
+        ids = torch.cat([pos, neg], 1).reshape(S, M6).to(torch.int64)
         valid = (ids >= 0) & (ids < N)
-        step = torch.arange(S, device=dev).view(S, 1).expand(S, 6 * B)
-        key = (step * N + torch.where(valid, ids, torch.zeros_like(ids))).reshape(-1)
-        uniq, inverse = torch.unique(key, return_inverse=True)          # sorted by (step, id)
-        u_step, u_id = uniq // N, uniq % N
-        u_owner = u_id % G
-        k2 = u_step * G + u_owner
-        order = torch.argsort(k2, stable=True)                          # staging order (step, owner, id)
-        staged_id, staged_owner = u_id[order], u_owner[order]
-        counts = torch.bincount(k2, minlength=S * G).view(S, G)         # rows I need from owner g at step s
-        pos_in = torch.empty_like(order)
-        pos_in[order] = torch.arange(order.numel(), device=dev)
-        per_step = counts.sum(1)
-        step_start = torch.cumsum(per_step, 0) - per_step
-        remap = pos_in[inverse] - step_start[step.reshape(-1)]
+        idz = torch.where(valid, ids, torch.zeros_like(ids))            # invalid ids alias row 0; their slots stay empty
+        step = torch.arange(S, device=dev).view(S, 1)
+        key = ((step * G + idz % G) * N + idz).reshape(-1)              # sorts as (step, owner, id)
+        key_sorted, perm = torch.sort(key)
+        uniq, seg_sorted, cnt = torch.unique_consecutive(key_sorted, return_inverse=True, return_counts=True)
+        U = int(uniq.numel())
+        inverse = torch.empty_like(seg_sorted)
+        inverse[perm] = seg_sorted                                      # staged position (chunk-wide) of every slot
+        u_id = uniq % N
+        bounds = torch.searchsorted(uniq, torch.arange(S * G + 1, device=dev) * N)
+        counts = (bounds[1:] - bounds[:-1]).view(S, G)                  # rows I need from owner g at step s
+        step_start = bounds[:-1:G]                                      # [S] first staged position of each step
+        remap = inverse - step_start.view(S, 1).expand(S, M6).reshape(-1)
         remap = torch.where(valid.reshape(-1), remap, torch.full_like(remap, -1)).to(torch.int32).view(S, 2 * B, 3)
         # counts: what every peer wants from me, per step
         if G > 1:
             send_c = counts.t().contiguous()                            # [G,S]: row p -> peer p
             recv_c = torch.empty_like(send_c)
             dist.all_to_all_single(recv_c, send_c, group=self.group)
-            sc = counts.cpu()                                           # the one host sync of the chunk
-            rc = recv_c.t().contiguous().cpu()
+            both = torch.stack([counts, recv_c.t()]).cpu()              # the host sync for the split sizes
+            sc, rc = both[0], both[1]
         else:
             sc = rc = counts.cpu()
-        # id lists, grouped by destination peer (then step): one all-to-all for the chunk
-        order2 = torch.argsort(staged_owner, stable=True)
-        send_ids = (staged_id // G).to(torch.int32)[order2]
+        # id lists grouped by destination peer (then step): one all-to-all for the chunk
+        send_ids = (u_id // G).to(torch.int32)
+        if G > 1:
+            grouped = torch.empty_like(send_ids)
+            grouped[_regroup(U, counts)] = send_ids
+            send_ids = grouped
         recv_ids = self._a2a(send_ids, sc.sum(0).tolist(), rc.sum(0).tolist())
-        # received layout is (peer, step); per-step request lists need (step, peer)
-        seg_len = rc.t().contiguous().reshape(-1).to(dev)               # [G*S] lengths in (peer, step) order
-        seg = torch.repeat_interleave(torch.arange(G * S, device=dev), seg_len)
-        key3 = (seg % S) * G + seg // S
-        req_all = recv_ids[torch.argsort(key3, stable=True)]
+        n_req = int(recv_ids.numel())
+        rc_dev = rc.to(dev)
+        if G > 1:                                                       # received (peer, step) -> needed (step, peer)
+            req_all = torch.empty_like(recv_ids)
+            req_all[_regroup(n_req, rc_dev.t().contiguous())] = recv_ids
+        else:
+            req_all = recv_ids
+        per_step_req = rc_dev.sum(1)
+        req_start_dev = torch.cumsum(per_step_req, 0) - per_step_req
+        req_start = [0] + torch.cumsum(rc.sum(1), 0).tolist()
+        # pre-reduction items: the gradient slots (ge_hinge_grad order h+,t+,r+,h-,t-,r- per pair)
+        # that feed each staged row.  Slots that turn out empty at run time (hinge inactive, merged
+        # pos/neg rows, invalid ids) are skipped by the kernel through grad_idx < 0.
+        f = torch.arange(M6, device=dev)
+        tr, X = f // 3, f % 3
+        gslot = (tr % B) * 6 + (tr // B) * 3 + X
+        seg_bounds = torch.cat([step_start, torch.full((1,), U, dtype=torch.int64, device=dev)])
+        u_step = torch.repeat_interleave(torch.arange(S, device=dev), seg_bounds[1:] - seg_bounds[:-1], output_size=U)
+        reduce_items = segment_items(cnt, seg_bounds, torch.arange(U, device=dev) - step_start[u_step],
+                                     gslot[perm % M6])
+        # owner-apply items: the received gradient rows (one per requested (peer,row)) per shard row
+        rows_local = int(self.shard.shape[0])
+        req_step = torch.repeat_interleave(torch.arange(S, device=dev), per_step_req, output_size=n_req)
+        key4 = req_step * rows_local + req_all.to(torch.int64)
+        if G > 1:
+            key4_sorted, o2 = torch.sort(key4)
+        else:                                                           # one peer: each step's list is already sorted
+            key4_sorted, o2 = key4, torch.arange(n_req, device=dev)
+        useg, cnt4 = torch.unique_consecutive(key4_sorted, return_counts=True)
+        bounds4 = torch.searchsorted(useg, torch.arange(S + 1, device=dev) * rows_local)
+        apply_items = segment_items(cnt4, bounds4, useg % rows_local, o2 - req_start_dev[req_step[o2]])
+        own = int(sc[:, self.rank].sum())
         return ChunkPlan(S=S, B=B, sc=sc.tolist(), rc=rc.tolist(), remap=remap, req_all=req_all,
-                         req_start=[0] + torch.cumsum(rc.sum(1), 0).tolist(),
-                         unique_rows=int(per_step.sum()), remote_rows=int(per_step.sum() - counts[:, self.rank].sum()))
+                         req_start=req_start, reduce_items=reduce_items, apply_items=apply_items,
+                         unique_rows=U, remote_rows=U - own)
 
     def step_planned(self, plan: "ChunkPlan", s: int, lr: float) -> torch.Tensor:
         """Step s of a planned chunk: fetch rows (all-to-all), fused score/hinge/grad on the staging
@@ -172,10 +265,19 @@ class ShardedTrainer:
         remap = plan.remap[s]
         loss, gi, gv = self.k.hinge_grad(staged, remap[:B].contiguous(), remap[B:].contiguous(), lr,
                                          self.margin, self.model, self.max_norm)
-        gsum = torch.zeros_like(staged)
-        self.k.scatter_add_rows(gsum, gi, gv)                           # pre-reduce per staged row
+        gsum = torch.empty_like(staged)
+        ri = plan.reduce_items
+        i0, i1 = ri.item_start[s], ri.item_start[s + 1]
+        z0, z1 = ri.split_start[s], ri.split_start[s + 1]
+        if z1 > z0:
+            gsum.index_fill_(0, ri.split_rows[z0:z1], 0.0)              # split rows are combined atomically
+        self.k.segment_sum_rows(gv, gi, ri.order, ri.begin[i0:i1], ri.length[i0:i1], ri.target[i0:i1],
+                                gsum, False)                            # pre-reduce per staged row
         recv_g = self._a2a(gsum, sc, rc)                                # sums back to the owners
-        self.k.scatter_add_rows(self.shard, req, recv_g)
+        ai = plan.apply_items
+        i0, i1 = ai.item_start[s], ai.item_start[s + 1]
+        self.k.segment_sum_rows(recv_g, None, ai.order, ai.begin[i0:i1], ai.length[i0:i1], ai.target[i0:i1],
+                                self.shard, True)
         self.global_step += 1
         return loss
 

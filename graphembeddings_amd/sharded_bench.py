@@ -73,7 +73,7 @@ def run(args):
         return out
     timed_grad.pending = False
 
-    CHUNK = 16   # steps planned per exchange plan (one dedup / count exchange / host sync per chunk)
+    CHUNK = 64   # steps planned per exchange plan (one sort / count exchange / few host syncs per chunk)
 
     def lr_fn(gs):
         return H.inverse_time_decay(0.1, gs, decay_steps, 0.5)

@@ -103,6 +103,20 @@ int ge_scatter_add_rows(float* table, int64_t N, int32_t d, const int32_t* idx, 
 int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx, int64_t R,
                    float* out, void* stream);
 
+/* ge_segment_sum_rows: the atomic-free scatter for an index structure known ahead of time (the
+ * row-sharded path plans it once per chunk of steps; same ScatterSub semantics, holE.py:296).
+ * Work item i sums the source rows src[order[j]], j in [begin[i], begin[i]+len[i]), skipping
+ * order[j] < 0 and -- when src_idx is not NULL -- slots with src_idx[order[j]] < 0 (the empty
+ * IndexedSlices slots of ge_hinge_grad), into ONE destination row:
+ *   target[i] >= 0: out[target[i]]  = sum (accumulate = 0)  or  += sum (accumulate = 1), plain
+ *                   stores -- the caller guarantees no other item targets that row;
+ *   target[i] <  0: atomic add into out[~target[i]] (row split over several items; for
+ *                   accumulate = 0 the caller zeroes those rows first). */
+int ge_segment_sum_rows(const float* src, int64_t src_rows, const int32_t* src_idx,
+                        const int32_t* order, const int32_t* begin, const int32_t* len,
+                        const int32_t* target, int64_t n_items, int32_t d, float* out,
+                        int64_t out_rows, int32_t accumulate, void* stream);
+
 /* --- corrupt_batch (holE.py:152-153 -> 136-140 -> 97-133) fused with the per-batch host
  * resample of holE.py:343-347.  id_to_type [N] int32 type code per table row (-1 = unknown, the
  * reference's '?' default -> corrupted id -1, holE.py:39); type lists as CSR type_offsets

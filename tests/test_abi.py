@@ -18,7 +18,7 @@ def _declared():
 def test_header_declares_expected_entry_points():
     names = _declared()
     for must in ("ge_complex_score", "ge_hole_score", "ge_complex_hinge_step", "ge_hole_hinge_step",
-                 "ge_corrupt_batch", "ge_complex_score_1vK", "ge_hinge_grad", "ge_scatter_add_rows",
+                 "ge_corrupt_batch", "ge_complex_score_1vK", "ge_hinge_grad", "ge_scatter_add_rows", "ge_segment_sum_rows",
                  "ge_gather_rows", "ge_hinge_loss", "ge_version"):
         assert must in names
 

@@ -34,6 +34,10 @@ class OracleKernels:
     def hinge_grad(self, rows, pos, neg, lr, margin, model, max_norm):
         r = rows.numpy().astype(np.float64)
         idx, val, loss = O.hinge_grads(pos.numpy(), neg.numpy(), r, margin, max_norm, model)
+        # oracle blocks (r+, r-, t+, t-, h+, h-) x B  ->  the ABI's per-pair order h+, t+, r+, h-, t-, r-
+        B = pos.shape[0]
+        perm = (np.array([4, 2, 0, 5, 3, 1])[None, :] * B + np.arange(B)[:, None]).reshape(-1)
+        idx, val = idx[perm], val[perm]
         return (torch.as_tensor(loss.astype(np.float32)), torch.as_tensor(idx.astype(np.int32)),
                 torch.as_tensor((-lr * val).astype(rows.numpy().dtype)))
 
@@ -41,6 +45,23 @@ class OracleKernels:
         i = idx.numpy().astype(np.int64)
         t = table.numpy()
         np.add.at(t, i[i >= 0], val.numpy()[i >= 0])
+
+    def segment_sum_rows(self, src, src_idx, order, begin, length, target, out, accumulate):
+        """include/ge_hip.h ge_segment_sum_rows, item by item."""
+        o, srcn, outn = order.numpy(), src.numpy(), out.numpy()
+        si = None if src_idx is None else src_idx.numpy()
+        seen_plain = set()
+        for b, n, tg in zip(begin.numpy().tolist(), length.numpy().tolist(), target.numpy().tolist()):
+            acc = np.zeros(outn.shape[1], outn.dtype)
+            for s in o[b:b + n]:
+                if s >= 0 and (si is None or si[s] >= 0):
+                    acc += srcn[s]
+            if tg < 0:
+                outn[~tg] += acc
+            else:
+                assert tg not in seen_plain, "two plain items target one row"
+                seen_plain.add(tg)
+                outn[tg] = outn[tg] + acc if accumulate else acc
 
 
 def _free_port():
