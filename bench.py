@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--sharded", action="store_true", help="run the row-sharded (all-to-all) path even on 1 GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score-roofline", action="store_true")
+    ap.add_argument("--no-scaling-base", action="store_true",
+                    help="skip the 1-GPU run of the row-sharded config[3] workload that the N>1 lines are comparable to")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--entities", type=int, default=1_200_000)
     ap.add_argument("--triples", type=int, default=30_000_000)
@@ -231,6 +233,21 @@ def run_single(args):
         out["cpu_baseline"] = cpu_baseline_fb15k(fb, arrays, d, B, args.cpu_seconds)
     elif not args.no_cpu_baseline:
         out["cpu_baseline"] = None
+    if not args.no_scaling_base and args.workload == "auto" and args.model == "complex":
+        # The N>1 lines run BASELINE config[3] (960 MB table, row-sharded exchange) while this line is
+        # config[1] (13 MB table, no exchange): report the 1-GPU value of the N>1 workload beside it so
+        # weak-scaling efficiency can be read like for like (value(N) / (N * scaling_base.value)).
+        import copy
+        from graphembeddings_amd import sharded_bench
+        a2 = copy.copy(args)
+        a2.batch, a2.steps, a2.warmup = 16384, 128, 64
+        try:
+            sb = sharded_bench.run(a2, emit=False)
+            out["scaling_base"] = {"workload": sb["config"]["workload"], "batch_per_gpu": a2.batch, "value": sb["value"],
+                                   "unit": sb["unit"], "ms_per_step": sb["ms_per_step"], "n_gpus": 1,
+                                   "note": "same code path and per-GPU batch as `bench.py --gpus N` for N>1"}
+        except Exception as e:  # never lose the headline line to the auxiliary run
+            out["scaling_base"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out))
 
 

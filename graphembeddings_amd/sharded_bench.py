@@ -14,7 +14,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0
 
 
-def run(args):
+def run(args, emit=True):
     from . import data as D
     from . import hole as H
     from . import sharded as S
@@ -140,7 +140,9 @@ def run(args):
                          "algorithmic_bytes_per_launch": alg},
             "cpu_baseline": None,
         }
-        print(json.dumps(out), flush=True)
+        if emit:
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out if rank == 0 else None

@@ -7,9 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline > "$OUT/${TAG}_trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-scaling-base > "$OUT/${TAG}_trace.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_$C" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline > "$OUT/${TAG}_pmc_$C.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_$C" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-scaling-base > "$OUT/${TAG}_pmc_$C.log" 2>&1
 done
 python3 - "$OUT" "$TAG" "$*" <<'PY'
 import csv, glob, json, re, sys, collections
