@@ -33,15 +33,36 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+# per-source extra flags.  ge_hole.hip writes its packed fp32 math (v_pk_fma_f32) with explicit
+# 2-vectors; the SLP vectoriser would otherwise re-pair the scalar correlation into pairs that are
+# unaligned in LDS and re-read them with bank-conflicting ds_read2_b32.
+FILE_FLAGS = {"ge_hole.hip": ["-fno-slp-vectorize"]}
+OBJDIR = os.path.join(HERE, "_obj")
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    """Compile every HIP source into graphembeddings_amd/libge_hip.so. Returns the path."""
+    """Compile every HIP source (one object each, in parallel) and link graphembeddings_amd/libge_hip.so."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB + ".tmp"] + SOURCES
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = _hipcc()
+    common = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *extra_flags]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        cmd = [cc, *common, *FILE_FLAGS.get(src, []), "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
+    objs = []
+    for cmd, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    link = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link, cwd=CSRC)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

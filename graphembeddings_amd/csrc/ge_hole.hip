@@ -12,6 +12,13 @@
 // broadcast ds_read_b128 of a[i..i+3] and two conflict-free ds_read_b128 of b[i+k .. i+k+7] feed
 // 16 FMAs (3 LDS instructions per 16 FMAs, register-blocked 4x4).  d=200 is not a power of two
 // and needs no padding beyond rounding to a multiple of 4.
+// Where two correlations share the b operand (h star t and r star t), the a operands are stored
+// interleaved (h_i, r_i) and the pair (c_hr[q]) is accumulated with ONE v_pk_fma_f32 per (i, q):
+// (c1,c2) += (h_i, r_i) * b_{i+k+q} -- the packed halves are the two correlations, so every LDS
+// read stays a 16-byte aligned ds_read_b128 (4 reads per 16 packed FMAs = LDS 256 B/clk balanced
+// against the packed-fp32 rate).  This file is compiled with -fno-slp-vectorize (build.py): the SLP
+// vectoriser pairs the scalar form over adjacent lags instead, whose b pairs are unaligned for odd
+// i and get re-read with 4-way bank-conflicting ds_read2_b32 (measured 2x slower).
 // The gradients are three more correlations of the same shape:
 //   ds/dr_m = (h star t)_m     ds/dh_m = (r star t)_m     ds/dt_m = (rev(r) star h)_m,
 // with rev(r)_i = r_{(-i) mod d}  (so that sum_k r_k h_{(m-k)} becomes a correlation).
@@ -24,6 +31,17 @@ struct HoleFwd {
   float sc[3], inv[3];
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// One 16-byte aligned LDS read that stays ONE ds_read_b128: a volatile access is neither split into
+// dwords nor merged with the overlapping window of the next loop iteration (the optimiser otherwise
+// carries half of b across iterations and fetches the rest as bank-conflicting ds_read2_b32).
+__device__ __forceinline__ f4 lds_read16(const float* p) {
+  typedef const volatile __attribute__((address_space(3))) f4* lds_f4_ptr;
+  return *(lds_f4_ptr)p;   // explicit LDS address space: a volatile generic access would become a flat load
+}
+
 // 4 lags per lane per chunk: c[q] += sum_i a[i] * b[i + k0 + q]
 __device__ __forceinline__ void corr4(const float* __restrict__ a, const float* __restrict__ b, int d4,
                                       int k0, float (&c)[4]) {
@@ -31,9 +49,9 @@ __device__ __forceinline__ void corr4(const float* __restrict__ a, const float* 
   const float* bk = b + k0;
 #pragma unroll 2
   for (int i = 0; i < d4; i += 4) {
-    const float4 av = *reinterpret_cast<const float4*>(a + i);
-    const float4 b0 = *reinterpret_cast<const float4*>(bk + i);
-    const float4 b1 = *reinterpret_cast<const float4*>(bk + i + 4);
+    const f4 av = lds_read16(a + i);
+    const f4 b0 = lds_read16(bk + i);
+    const f4 b1 = lds_read16(bk + i + 4);
     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     const float aa[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
@@ -43,28 +61,30 @@ __device__ __forceinline__ void corr4(const float* __restrict__ a, const float* 
   }
 }
 
-// Two correlations against the same doubled operand b in one pass (shares the b reads):
-// c1[q] += sum_i a1[i] b[i+k0+q],  c2[q] += sum_i a2[i] b[i+k0+q]   -- 4 LDS reads per 32 FMAs.
-__device__ __forceinline__ void corr4x2(const float* __restrict__ a1, const float* __restrict__ a2,
-                                        const float* __restrict__ b, int d4, int k0, float (&c1)[4],
-                                        float (&c2)[4]) {
-  c1[0] = c1[1] = c1[2] = c1[3] = 0.f;
-  c2[0] = c2[1] = c2[2] = c2[3] = 0.f;
+// Two correlations against the same doubled operand b in one pass:
+// c[q] = (c1[q], c2[q]),  c1[q] += sum_i a1[i] b[i+k0+q],  c2[q] += sum_i a2[i] b[i+k0+q],
+// with a12 = interleaved (a1[i], a2[i]) pairs -- 4 aligned 16-byte LDS reads per 16 packed FMAs.
+__device__ __forceinline__ void corr4x2(const float* __restrict__ a12, const float* __restrict__ b, int d4,
+                                        int k0, float (&c1)[4], float (&c2)[4]) {
+  f2 c[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = f2{0.f, 0.f};
   const float* bk = b + k0;
 #pragma unroll 2
   for (int i = 0; i < d4; i += 4) {
-    const float4 u = *reinterpret_cast<const float4*>(a1 + i);
-    const float4 v = *reinterpret_cast<const float4*>(a2 + i);
-    const float4 b0 = *reinterpret_cast<const float4*>(bk + i);
-    const float4 b1 = *reinterpret_cast<const float4*>(bk + i + 4);
+    const f4 p0 = lds_read16(a12 + 2 * i);
+    const f4 p1 = lds_read16(a12 + 2 * i + 4);
+    const f4 b0 = lds_read16(bk + i);
+    const f4 b1 = lds_read16(bk + i + 4);
     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    const float uu[4] = {u.x, u.y, u.z, u.w};
-    const float vv[4] = {v.x, v.y, v.z, v.w};
+    const f2 aa[4] = {f2{p0.x, p0.y}, f2{p0.z, p0.w}, f2{p1.x, p1.y}, f2{p1.z, p1.w}};
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { c1[q] += uu[w] * bb[w + q]; c2[q] += vv[w] * bb[w + q]; }
+      for (int q = 0; q < 4; ++q) c[q] = __builtin_elementwise_fma(aa[w], f2{bb[w + q], bb[w + q]}, c[q]);
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { c1[q] = c[q].x; c2[q] = c[q].y; }
 }
 
 // Stage one triple's rows in this wave's LDS slice and run the correlations.
@@ -75,7 +95,7 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
                                           float max_norm, HoleFwd& f, float (&Gr)[NCH][4],
                                           float (&Gh)[NCH][4], float (&Gt)[NCH][4]) {
   const int LB = d4 + NCH * 256;
-  float* a_h = lds;
+  float* a_h = lds;               // !GRAD: h[d4] r[d4];   GRAD: interleaved (h_i, r_i)[2*d4]
   float* a_r = a_h + d4;
   float* a_rr = a_r + d4;
   float* b_t = a_rr + d4;
@@ -87,9 +107,14 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
   for (int j = lane; j < d4; j += kWave) {
     const bool in = j < d;
     const float vh = in ? xh[j] : 0.f, vr = in ? xr[j] : 0.f, vt = in ? xt[j] : 0.f;
-    a_h[j] = vh;
-    a_r[j] = vr;
-    if (GRAD) a_rr[j] = in ? xr[j == 0 ? 0 : d - j] : 0.f;
+    if (GRAD) {
+      a_h[2 * j] = vh;
+      a_h[2 * j + 1] = vr;
+      a_rr[j] = in ? xr[j == 0 ? 0 : d - j] : 0.f;
+    } else {
+      a_h[j] = vh;
+      a_r[j] = vr;
+    }
     ssh += vh * vh; ssr += vr * vr; sst += vt * vt;
   }
   for (int j = lane; j < LB; j += kWave) {
@@ -104,14 +129,19 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
   for (int c = 0; c < NCH; ++c) {
     const int k0 = c * 256 + 4 * lane;
     if (k0 < d4) {
+      float rv[4];
       if (GRAD) {
-        corr4x2(a_h, a_r, b_t, d4, k0, Gr[c], Gh[c]);  // (h star t) = ds/dr and (r star t) = ds/dh
+        corr4x2(a_h, b_t, d4, k0, Gr[c], Gh[c]);       // (h star t) = ds/dr and (r star t) = ds/dh
         corr4(a_rr, b_h, d4, k0, Gt[c]);               // (rev r star h) = ds/dt
+        const float4 u = *reinterpret_cast<const float4*>(a_h + 2 * k0);
+        const float4 v = *reinterpret_cast<const float4*>(a_h + 2 * k0 + 4);
+        rv[0] = u.y; rv[1] = u.w; rv[2] = v.y; rv[3] = v.w;
       } else {
         corr4(a_h, b_t, d4, k0, Gr[c]);                // (h star t): the score
+        const float4 u = *reinterpret_cast<const float4*>(a_r + k0);
+        rv[0] = u.x; rv[1] = u.y; rv[2] = u.z; rv[3] = u.w;
       }
-      const float4 rv = *reinterpret_cast<const float4*>(a_r + k0);
-      part += rv.x * Gr[c][0] + rv.y * Gr[c][1] + rv.z * Gr[c][2] + rv.w * Gr[c][3];
+      part += rv[0] * Gr[c][0] + rv[1] * Gr[c][1] + rv[2] * Gr[c][2] + rv[3] * Gr[c][3];
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { Gr[c][q] = 0.f; Gh[c][q] = 0.f; Gt[c][q] = 0.f; }
@@ -202,7 +232,7 @@ __device__ __forceinline__ HCoef hole_coef(float coef, const HoleFwd& f, int X, 
 
 // IndexedSlices of d(sum_i L_i)/d(rows) * (-lr); slot order h+, t+, r+, h-, t-, r- (see ge_hip.h).
 template <int NCH>
-__global__ __launch_bounds__(kBlock) void hole_hinge_grad_kernel(
+__global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kernel(
     const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val) {
