@@ -104,24 +104,50 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
   const float* xt = rows + (int64_t)id[1] * d;
   const float* xr = rows + (int64_t)id[2] * d;
   float ssh = 0.f, sst = 0.f, ssr = 0.f;
-  for (int j = lane; j < d4; j += kWave) {
-    const bool in = j < d;
-    const float vh = in ? xh[j] : 0.f, vr = in ? xr[j] : 0.f, vt = in ? xt[j] : 0.f;
-    if (GRAD) {
-      a_h[2 * j] = vh;
-      a_h[2 * j + 1] = vr;
-      a_rr[j] = in ? xr[j == 0 ? 0 : d - j] : 0.f;
-    } else {
-      a_h[j] = vh;
-      a_r[j] = vr;
+  if ((d & 3) == 0) {
+    // 16-byte path (d == d4): one float4 per lane and row; the doubled operand needs exactly two copies
+    // (the largest index read is k0 + i + 7 <= 2d - 1).
+    for (int c4 = lane; c4 < (d >> 2); c4 += kWave) {
+      const float4 h4 = *reinterpret_cast<const float4*>(xh + 4 * c4);
+      const float4 t4 = *reinterpret_cast<const float4*>(xt + 4 * c4);
+      const float4 r4 = *reinterpret_cast<const float4*>(xr + 4 * c4);
+      ssh += h4.x * h4.x + h4.y * h4.y + h4.z * h4.z + h4.w * h4.w;
+      sst += t4.x * t4.x + t4.y * t4.y + t4.z * t4.z + t4.w * t4.w;
+      ssr += r4.x * r4.x + r4.y * r4.y + r4.z * r4.z + r4.w * r4.w;
+      if (GRAD) {
+        *reinterpret_cast<float4*>(a_h + 8 * c4) = make_float4(h4.x, r4.x, h4.y, r4.y);
+        *reinterpret_cast<float4*>(a_h + 8 * c4 + 4) = make_float4(h4.z, r4.z, h4.w, r4.w);
+        const float* rr = xr + d - 4 * c4;   // rev(r)_j = r_{(d - j) mod d}, j = 4*c4 + m
+        *reinterpret_cast<float4*>(a_rr + 4 * c4) = make_float4(c4 == 0 ? xr[0] : rr[0], rr[-1], rr[-2], rr[-3]);
+        *reinterpret_cast<float4*>(b_h + 4 * c4) = h4;
+        *reinterpret_cast<float4*>(b_h + d + 4 * c4) = h4;
+      } else {
+        *reinterpret_cast<float4*>(a_h + 4 * c4) = h4;
+        *reinterpret_cast<float4*>(a_r + 4 * c4) = r4;
+      }
+      *reinterpret_cast<float4*>(b_t + 4 * c4) = t4;
+      *reinterpret_cast<float4*>(b_t + d + 4 * c4) = t4;
     }
-    ssh += vh * vh; ssr += vr * vr; sst += vt * vt;
-  }
-  for (int j = lane; j < LB; j += kWave) {
-    int jm = j;
-    while (jm >= d) jm -= d;
-    b_t[j] = xt[jm];
-    if (GRAD) b_h[j] = xh[jm];
+  } else {
+    for (int j = lane; j < d4; j += kWave) {
+      const bool in = j < d;
+      const float vh = in ? xh[j] : 0.f, vr = in ? xr[j] : 0.f, vt = in ? xt[j] : 0.f;
+      if (GRAD) {
+        a_h[2 * j] = vh;
+        a_h[2 * j + 1] = vr;
+        a_rr[j] = in ? xr[j == 0 ? 0 : d - j] : 0.f;
+      } else {
+        a_h[j] = vh;
+        a_r[j] = vr;
+      }
+      ssh += vh * vh; ssr += vr * vr; sst += vt * vt;
+    }
+    for (int j = lane; j < LB; j += kWave) {
+      int jm = j;
+      while (jm >= d) jm -= d;
+      b_t[j] = xt[jm];
+      if (GRAD) b_h[j] = xh[jm];
+    }
   }
   __syncthreads();
   float part = 0.f;
@@ -280,6 +306,25 @@ __global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kern
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int k0 = c * 256 + 4 * lane;
+        if ((d & 3) == 0) {                       // 16-byte path: the lane's 4 lags are one float4
+          if (k0 >= d) continue;
+          const float4 p4 = *reinterpret_cast<const float4*>(xp + k0);
+          const float4 n4 = *reinterpret_cast<const float4*>(xn + k0);
+          const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, nv[4] = {n4.x, n4.y, n4.z, n4.w};
+          float vp[4], vn[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vp[q] = kp.alpha * GP[X][c][q] + kp.beta * pv[q];
+            vn[q] = kn.alpha * GN[X][c][q] + kn.beta * nv[q];
+          }
+          if (same) {
+            *reinterpret_cast<float4*>(gp + k0) = make_float4(vp[0] + vn[0], vp[1] + vn[1], vp[2] + vn[2], vp[3] + vn[3]);
+          } else {
+            *reinterpret_cast<float4*>(gp + k0) = make_float4(vp[0], vp[1], vp[2], vp[3]);
+            *reinterpret_cast<float4*>(gn + k0) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+          }
+          continue;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int kk = k0 + q;
