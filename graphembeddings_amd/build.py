@@ -46,7 +46,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     cc = _hipcc()
-    common = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *extra_flags]
+    common = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *extra_flags,
+              *os.environ.get("GE_CXXFLAGS", "").split()]
     procs = []
     for src in SOURCES:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
