@@ -16,14 +16,14 @@ import csv, glob, json, re, sys, collections
 out, tag, args = sys.argv[1], sys.argv[2], sys.argv[3]
 stats = glob.glob(f"{out}/{tag}_trace/*/*_kernel_stats.csv")
 with open(f"{out}/{tag}_kernel_stats.csv", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {args} --no-cpu-baseline\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {args} --no-cpu-baseline --no-scaling-base\n")
     if stats:
         for i, row in enumerate(csv.reader(open(stats[0]))):
             row[0] = re.sub(r"\(.*", "", row[0])[:100]
             if i == 0 or "ge::" in row[0]:
                 f.write(",".join(row) + "\n")
 bench_line = [l for l in open(f"{out}/{tag}_trace.log") if l.startswith("{")]
-pmc = {"_command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py {args} --no-cpu-baseline (one pass per counter)",
+pmc = {"_command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py {args} --no-cpu-baseline --no-scaling-base (one pass per counter)",
        "_units": "counter values in KB per launch (mean over launches); FETCH_SIZE doubled in hbm_bytes_corrected per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
 agg = collections.defaultdict(dict)
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
