@@ -185,7 +185,10 @@ def test_all_inactive_margin_leaves_table_bit_identical(H, G):
 
 
 # ---------------------------------------------------------------- config-2 size against the C port
-@pytest.mark.parametrize("model,d,B", [("complex", 200, 4096), ("complex", 50, 128), ("hole", 200, 1024)])
+@pytest.mark.parametrize("model,d,B", [("complex", 200, 4096), ("complex", 50, 128), ("hole", 200, 1024),
+                                       # HolE beyond one 256-lag chunk: 16-byte path (300) and the generic path (258, 67)
+                                       ("hole", 300, 96), ("hole", 258, 64), ("hole", 67, 64), ("hole", 512, 32),
+                                       ("complex", 1024, 64), ("complex", 6, 64)])
 def test_step_at_baseline_sizes_against_c_port(H, model, d, B):
     from graphembeddings_amd import data as D
     fb = D.fb15k_shape()
