@@ -158,15 +158,28 @@ int oracle_hinge_step(float *table, int64_t N, int32_t d, const int32_t *pos, co
                       int64_t B, float margin, float lr, float max_norm, int hole, float *loss,
                       int threads) {
     if (d <= 0 || (!hole && (d & 1))) return -22;
-    float *G = (float *)malloc(sizeof(float) * 6 * (size_t)B * d);
-    if (!G) return -12;
+    /* the gradient buffer is kept between calls: a fresh 20 MB malloc per step is first-touched by
+     * every thread at once, and the page-fault storm made 8 threads slower than 1 */
+    static float *G = NULL;
+    static size_t G_cap = 0;
+    const size_t need = sizeof(float) * 6 * (size_t)B * d;
+    if (need > G_cap) {
+        free(G);
+        G = (float *)malloc(need);
+        G_cap = G ? need : 0;
+        if (!G) return -12;
+        memset(G, 0, need);
+    }
+    const int T = threads > 0 ? threads : 1;
 #ifdef _OPENMP
-#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+#pragma omp parallel num_threads(T)
 #endif
     {
-        float *buf = (float *)malloc(sizeof(float) * 9 * (size_t)d);
-        float *yh = buf, *yt = buf + d, *yr = buf + 2 * d, *gh = buf + 3 * d, *gt = buf + 4 * d, *gr = buf + 5 * d;
-        float *yh2 = buf + 6 * d, *yt2 = buf + 7 * d, *yr2 = buf + 8 * d;
+        float buf[9 * 1024];
+        float *heap = d > 1024 ? (float *)malloc(sizeof(float) * 9 * (size_t)d) : NULL;
+        float *b0 = heap ? heap : buf;
+        float *yh = b0, *yt = b0 + d, *yr = b0 + 2 * d, *gh = b0 + 3 * d, *gt = b0 + 4 * d, *gr = b0 + 5 * d;
+        float *yh2 = b0 + 6 * d, *yt2 = b0 + 7 * d, *yr2 = b0 + 8 * d;
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif
@@ -191,21 +204,29 @@ int oracle_hinge_step(float *table, int64_t N, int32_t d, const int32_t *pos, co
             clip_backward(table + (int64_t)n[1] * d, ssn[1], max_norm, gt, g + 3 * d, d);
             clip_backward(table + (int64_t)n[0] * d, ssn[0], max_norm, gh, g + 5 * d, d);
         }
-        free(buf);
-    }
-    /* ScatterSub, serial, in concat order (slot-major) */
-    static const int col_of_slot[6] = {2, 2, 1, 1, 0, 0};
-    for (int slot = 0; slot < 6; ++slot) {
-        const int32_t *src = (slot & 1) ? neg : pos;
-        for (int64_t i = 0; i < B; ++i) {
-            if (loss[i] != loss[i]) continue;
-            float *row = table + (int64_t)src[3 * i + col_of_slot[slot]] * d;
-            const float *g = G + ((size_t)i * 6 + slot) * d;
-            for (int j = 0; j < d; ++j) row[j] -= lr * g[j];
+        free(heap);
+        /* ScatterSub in concat order (slot-major).  Every thread walks the whole index list but applies
+         * only the rows it owns (row % T == tid): per row the order of the subtractions is exactly the
+         * serial one, so the result does not depend on the thread count.  (The implicit barrier of the
+         * omp for above guarantees all gradients were computed against the pre-step table.) */
+        static const int col_of_slot[6] = {2, 2, 1, 1, 0, 0};
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+        const int tid = 0, nth = 1;
+#endif
+        for (int slot = 0; slot < 6; ++slot) {
+            const int32_t *src = (slot & 1) ? neg : pos;
+            for (int64_t i = 0; i < B; ++i) {
+                if (loss[i] != loss[i]) continue;
+                const int32_t r = src[3 * i + col_of_slot[slot]];
+                if (r % nth != tid) continue;
+                float *row = table + (int64_t)r * d;
+                const float *g = G + ((size_t)i * 6 + slot) * d;
+                for (int j = 0; j < d; ++j) row[j] -= lr * g[j];
+            }
         }
     }
-    free(G);
-    (void)threads;
     return 0;
 }
 
