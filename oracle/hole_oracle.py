@@ -154,6 +154,34 @@ def hole_score_direct(triples, table, max_norm: float = 1.0) -> np.ndarray:
     return out
 
 
+def hole_graph20170724_evaluate(triples, table, max_norm: float = 1.0) -> np.ndarray:
+    """Compatibility restatement of the HISTORICAL HolE variant recorded in the reference's
+    holE-20170724/graph.pbtxt:6221-6521 (not what holE.py computes today; oracle-only, no kernel):
+    rows as k = d/2 complex numbers (get_embedding, holE.py:161-168), then the op chain
+    FFT(h), Conj, FFT(t), Mul, IFFT  ->  c = complex circular correlation, c_m = sum_i conj(h_i) t_{(i+m) mod k};
+    Mul(r, c); Real + Imag; Sum over m; Tanh.  Returns tanh(score) [B,1]."""
+    triples = np.asarray(triples)
+    h = get_embedding(triples[:, 0], table, max_norm)
+    t = get_embedding(triples[:, 1], table, max_norm)
+    r = get_embedding(triples[:, 2], table, max_norm)
+    c = np.fft.ifft(np.conj(np.fft.fft(h, axis=1)) * np.fft.fft(t, axis=1), axis=1)
+    p = r * c
+    return np.tanh(np.sum(p.real + p.imag, axis=1))[:, None]
+
+
+def hole_graph20170724_evaluate_direct(triples, table, max_norm: float = 1.0) -> np.ndarray:
+    """O(k^2) definition of the same quantity (cross-check of the FFT form)."""
+    triples = np.asarray(triples)
+    h = get_embedding(triples[:, 0], table, max_norm)
+    t = get_embedding(triples[:, 1], table, max_norm)
+    r = get_embedding(triples[:, 2], table, max_norm)
+    k = h.shape[1]
+    idx = (np.arange(k)[:, None] + np.arange(k)[None, :]) % k           # [i, m] -> (i+m) % k
+    c = np.einsum("bi,bim->bm", np.conj(h), t[:, idx])
+    p = r * c
+    return np.tanh(np.sum(p.real + p.imag, axis=1))[:, None]
+
+
 def hole_evaluate_triples(triples, table, max_norm: float = 1.0):
     return sigmoid(hole_score(triples, table, max_norm))[:, None]
 

@@ -268,3 +268,16 @@ def test_logloss_step_matches_torch_autograd(G):
     lvec.sum().backward()
     assert np.abs(loss - lvec.detach().numpy()).max() < 1e-10
     assert np.abs(new - (emb.detach() - lr * emb.grad).numpy()).max() < 1e-12
+
+
+def test_historical_hole_graph_variant_fft_equals_direct():
+    """The 2017-07-24 graph's HolE (complex FFT correlation, Re+Im, tanh; graph.pbtxt:6221-6521) is kept in
+    the oracle as a documented compatibility restatement: its FFT form equals the O(k^2) definition."""
+    rng = np.random.default_rng(3)
+    for d in (50, 128, 200):
+        table = rng.standard_normal((40, d)) * rng.uniform(0.02, 0.3, (40, 1))
+        tr = rng.integers(0, 40, (64, 3))
+        a = O.hole_graph20170724_evaluate(tr, table)
+        b = O.hole_graph20170724_evaluate_direct(tr, table)
+        assert a.shape == (64, 1) and np.abs(a - b).max() < 1e-12
+        assert np.all(np.abs(a) < 1.0)
