@@ -87,19 +87,31 @@ __device__ __forceinline__ void corr4x2(const float* __restrict__ a12, const flo
   for (int q = 0; q < 4; ++q) { c1[q] = c[q].x; c2[q] = c[q].y; }
 }
 
-// Stage one triple's rows in this wave's LDS slice and run the correlations.
-// LDS slice layout (floats): a_h[d4] a_r[d4] a_rr[d4] b_t[LB] b_h[LB],  LB = d4 + NCH*256.
+// A wavefront's LDS slice is private to it, so the staging -> correlation hand-off needs ordering only
+// inside the wave: its LDS operations execute in program order; the fence stops the compiler from
+// moving accesses across the hand-off.  (No workgroup barrier: waves whose pair is hinge-inactive
+// leave early.)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS slice of one wavefront (floats):  A[2*d4]  B[LB],  LB = d4 + NCH*256.
+//   forward  (score, and phase 1 of the gradient): A = h and r (GRAD: interleaved (h_i, r_i)), B = t doubled
+//   backward (phase 2 of the gradient, active pairs only): A = rev(r) [d4], B = h doubled
+__device__ __forceinline__ int hole_slice_floats(int d4, int nch) { return 2 * d4 + d4 + nch * 256; }
+
+// Phase 1: stage h, r, t; (h star t) [and (r star t) when GRAD]; raw score, clip scales, sigmoid.
 template <int NCH, bool GRAD>
-__device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d, int d4,
-                                          const int32_t (&id)[3], float* __restrict__ lds, int lane,
-                                          float max_norm, HoleFwd& f, float (&Gr)[NCH][4],
-                                          float (&Gh)[NCH][4], float (&Gt)[NCH][4]) {
+__device__ __forceinline__ void hole_forward(const float* __restrict__ rows, int d, int d4,
+                                             const int32_t (&id)[3], float* __restrict__ lds, int lane,
+                                             float max_norm, HoleFwd& f, float (&Gr)[NCH][4],
+                                             float (&Gh)[NCH][4]) {
   const int LB = d4 + NCH * 256;
   float* a_h = lds;               // !GRAD: h[d4] r[d4];   GRAD: interleaved (h_i, r_i)[2*d4]
   float* a_r = a_h + d4;
-  float* a_rr = a_r + d4;
-  float* b_t = a_rr + d4;
-  float* b_h = b_t + LB;
+  float* b_t = a_h + 2 * d4;
   const float* xh = rows + (int64_t)id[0] * d;
   const float* xt = rows + (int64_t)id[1] * d;
   const float* xr = rows + (int64_t)id[2] * d;
@@ -117,10 +129,6 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
       if (GRAD) {
         *reinterpret_cast<float4*>(a_h + 8 * c4) = make_float4(h4.x, r4.x, h4.y, r4.y);
         *reinterpret_cast<float4*>(a_h + 8 * c4 + 4) = make_float4(h4.z, r4.z, h4.w, r4.w);
-        const float* rr = xr + d - 4 * c4;   // rev(r)_j = r_{(d - j) mod d}, j = 4*c4 + m
-        *reinterpret_cast<float4*>(a_rr + 4 * c4) = make_float4(c4 == 0 ? xr[0] : rr[0], rr[-1], rr[-2], rr[-3]);
-        *reinterpret_cast<float4*>(b_h + 4 * c4) = h4;
-        *reinterpret_cast<float4*>(b_h + d + 4 * c4) = h4;
       } else {
         *reinterpret_cast<float4*>(a_h + 4 * c4) = h4;
         *reinterpret_cast<float4*>(a_r + 4 * c4) = r4;
@@ -135,7 +143,6 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
       if (GRAD) {
         a_h[2 * j] = vh;
         a_h[2 * j + 1] = vr;
-        a_rr[j] = in ? xr[j == 0 ? 0 : d - j] : 0.f;
       } else {
         a_h[j] = vh;
         a_r[j] = vr;
@@ -146,10 +153,9 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
       int jm = j;
       while (jm >= d) jm -= d;
       b_t[j] = xt[jm];
-      if (GRAD) b_h[j] = xh[jm];
     }
   }
-  __syncthreads();
+  wave_lds_sync();
   float part = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -158,7 +164,6 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
       float rv[4];
       if (GRAD) {
         corr4x2(a_h, b_t, d4, k0, Gr[c], Gh[c]);       // (h star t) = ds/dr and (r star t) = ds/dh
-        corr4(a_rr, b_h, d4, k0, Gt[c]);               // (rev r star h) = ds/dt
         const float4 u = *reinterpret_cast<const float4*>(a_h + 2 * k0);
         const float4 v = *reinterpret_cast<const float4*>(a_h + 2 * k0 + 4);
         rv[0] = u.y; rv[1] = u.w; rv[2] = v.y; rv[3] = v.w;
@@ -170,7 +175,7 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
       part += rv[0] * Gr[c][0] + rv[1] * Gr[c][1] + rv[2] * Gr[c][2] + rv[3] * Gr[c][3];
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { Gr[c][q] = 0.f; Gh[c][q] = 0.f; Gt[c][q] = 0.f; }
+      for (int q = 0; q < 4; ++q) { Gr[c][q] = 0.f; Gh[c][q] = 0.f; }
     }
   }
   f.s_raw = group_sum<kWave>(part);
@@ -180,7 +185,46 @@ __device__ __forceinline__ void hole_side(const float* __restrict__ rows, int d,
   f.sc[2] = clip_scale(ssr, max_norm, f.inv[2]);
   f.s = f.s_raw * f.sc[0] * f.sc[1] * f.sc[2];
   f.sig = sigmoidf_dev(f.s);
-  __syncthreads();  // LDS slice is reused by the next side / next triple
+  wave_lds_sync();  // the slice is reused by the next side / phase / triple
+}
+
+// Phase 2 (hinge-active pairs only): stage rev(r) and h doubled; (rev r star h) = ds/dt.
+template <int NCH>
+__device__ __forceinline__ void hole_backward_t(const float* __restrict__ rows, int d, int d4,
+                                                const int32_t (&id)[3], float* __restrict__ lds, int lane,
+                                                float (&Gt)[NCH][4]) {
+  const int LB = d4 + NCH * 256;
+  float* a_rr = lds;
+  float* b_h = lds + 2 * d4;
+  const float* xh = rows + (int64_t)id[0] * d;
+  const float* xr = rows + (int64_t)id[2] * d;
+  if ((d & 3) == 0) {
+    for (int c4 = lane; c4 < (d >> 2); c4 += kWave) {
+      const float4 h4 = *reinterpret_cast<const float4*>(xh + 4 * c4);
+      const float* rr = xr + d - 4 * c4;   // rev(r)_j = r_{(d - j) mod d}, j = 4*c4 + m
+      *reinterpret_cast<float4*>(a_rr + 4 * c4) = make_float4(c4 == 0 ? xr[0] : rr[0], rr[-1], rr[-2], rr[-3]);
+      *reinterpret_cast<float4*>(b_h + 4 * c4) = h4;
+      *reinterpret_cast<float4*>(b_h + d + 4 * c4) = h4;
+    }
+  } else {
+    for (int j = lane; j < d4; j += kWave) a_rr[j] = j < d ? xr[j == 0 ? 0 : d - j] : 0.f;
+    for (int j = lane; j < LB; j += kWave) {
+      int jm = j;
+      while (jm >= d) jm -= d;
+      b_h[j] = xh[jm];
+    }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k0 = c * 256 + 4 * lane;
+    if (k0 < d4) corr4(a_rr, b_h, d4, k0, Gt[c]);
+    else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Gt[c][q] = 0.f;
+    }
+  }
+  wave_lds_sync();
 }
 
 __device__ __forceinline__ bool hbad3(int64_t N, const int32_t (&t)[3]) {
@@ -193,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void hole_score_kernel(
     float max_norm, int apply_sigmoid, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d4 = (d + 3) & ~3;
-  const int per_wave = 3 * d4 + 2 * (d4 + NCH * 256);
+  const int per_wave = hole_slice_floats(d4, NCH);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
   float* lds = smem + w * per_wave;
   constexpr int WPB = kBlock / kWave;
@@ -205,8 +249,8 @@ __global__ __launch_bounds__(kBlock) void hole_score_kernel(
     const bool bad = hbad3(N, id);
     if (bad) { id[0] = id[1] = id[2] = 0; }
     HoleFwd f;
-    float Gr[NCH][4], Gh[NCH][4], Gt[NCH][4];
-    hole_side<NCH, false>(table, d, d4, id, lds, lane, max_norm, f, Gr, Gh, Gt);
+    float Gr[NCH][4], Gh[NCH][4];
+    hole_forward<NCH, false>(table, d, d4, id, lds, lane, max_norm, f, Gr, Gh);
     if (live && lane == 0) out[g] = bad ? __builtin_nanf("") : (apply_sigmoid ? f.sig : f.s);
   }
 }
@@ -218,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void hole_hinge_loss_kernel(
     float* __restrict__ loss, float* __restrict__ sig_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d4 = (d + 3) & ~3;
-  const int per_wave = 3 * d4 + 2 * (d4 + NCH * 256);
+  const int per_wave = hole_slice_floats(d4, NCH);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
   float* lds = smem + w * per_wave;
   constexpr int WPB = kBlock / kWave;
@@ -233,9 +277,9 @@ __global__ __launch_bounds__(kBlock) void hole_hinge_loss_kernel(
     const bool bad = hbad3(N, p) || hbad3(N, n);
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
     HoleFwd fp, fn;
-    float Gr[NCH][4], Gh[NCH][4], Gt[NCH][4];
-    hole_side<NCH, false>(table, d, d4, p, lds, lane, max_norm, fp, Gr, Gh, Gt);
-    hole_side<NCH, false>(table, d, d4, n, lds, lane, max_norm, fn, Gr, Gh, Gt);
+    float Gr[NCH][4], Gh[NCH][4];
+    hole_forward<NCH, false>(table, d, d4, p, lds, lane, max_norm, fp, Gr, Gh);
+    hole_forward<NCH, false>(table, d, d4, n, lds, lane, max_norm, fn, Gr, Gh);
     if (live && lane == 0) {
       const float nanv = __builtin_nanf("");
       loss[g] = bad ? nanv : fmaxf(fp.sig - fn.sig + margin, 0.f);
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kern
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d4 = (d + 3) & ~3;
-  const int per_wave = 3 * d4 + 2 * (d4 + NCH * 256);
+  const int per_wave = hole_slice_floats(d4, NCH);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
   float* lds = smem + w * per_wave;
   constexpr int WPB = kBlock / kWave;
@@ -282,11 +326,17 @@ __global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kern
     HoleFwd fp, fn;
     // G[side][X]: X = 0 h, 1 t, 2 r
     float GP[3][NCH][4], GN[3][NCH][4];
-    hole_side<NCH, true>(rows, d, d4, p, lds, lane, max_norm, fp, GP[2], GP[0], GP[1]);
-    hole_side<NCH, true>(rows, d, d4, n, lds, lane, max_norm, fn, GN[2], GN[0], GN[1]);
+    hole_forward<NCH, true>(rows, d, d4, p, lds, lane, max_norm, fp, GP[2], GP[0]);
+    hole_forward<NCH, true>(rows, d, d4, n, lds, lane, max_norm, fn, GN[2], GN[0]);
     const float pre = fp.sig - fn.sig + margin;
     const bool on = live && !bad && (pre >= 0.f);
     if (live && lane == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
+    if (!on) {   // wave-uniform: the pair's gradient is exactly zero -- no third correlation, empty slots
+      if (live && lane < 6) grad_idx[g * 6 + lane] = -1;
+      continue;
+    }
+    hole_backward_t<NCH>(rows, d, d4, p, lds, lane, GP[1]);
+    hole_backward_t<NCH>(rows, d, d4, n, lds, lane, GN[1]);
     const float cp = fp.sig * (1.f - fp.sig), cn = -fn.sig * (1.f - fn.sig);
 #pragma unroll
     for (int X = 0; X < 3; ++X) {
@@ -341,7 +391,7 @@ __global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kern
 
 static inline size_t hole_lds_bytes(int d, int nch) {
   const int d4 = (d + 3) & ~3;
-  return sizeof(float) * (size_t)(kBlock / kWave) * (3 * d4 + 2 * (d4 + nch * 256));
+  return sizeof(float) * (size_t)(kBlock / kWave) * (size_t)(2 * d4 + d4 + nch * 256);
 }
 
 int hole_max_dim() { return 512; }
