@@ -47,8 +47,18 @@ __device__ __forceinline__ void corr4(const float* __restrict__ a, const float* 
                                       int k0, float (&c)[4]) {
   c[0] = c[1] = c[2] = c[3] = 0.f;
   const float* bk = b + k0;
-#pragma unroll 2
-  for (int i = 0; i < d4; i += 4) {
+  int i = 0;
+  for (; i + 8 <= d4; i += 8) {   // 8 i per step: 5 LDS reads per 32 FMAs (the 11-float window of b is 3 reads)
+    const f4 a0 = lds_read16(a + i), a1 = lds_read16(a + i + 4);
+    const f4 b0 = lds_read16(bk + i), b1 = lds_read16(bk + i + 4), b2 = lds_read16(bk + i + 8);
+    const float bb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+    const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] += aa[u] * bb[u + q];
+  }
+  for (; i < d4; i += 4) {
     const f4 av = lds_read16(a + i);
     const f4 b0 = lds_read16(bk + i);
     const f4 b1 = lds_read16(bk + i + 4);
@@ -70,8 +80,20 @@ __device__ __forceinline__ void corr4x2(const float* __restrict__ a12, const flo
 #pragma unroll
   for (int q = 0; q < 4; ++q) c[q] = f2{0.f, 0.f};
   const float* bk = b + k0;
-#pragma unroll 2
-  for (int i = 0; i < d4; i += 4) {
+  int i = 0;
+  for (; i + 8 <= d4; i += 8) {   // 8 i per step: 7 LDS reads per 32 packed FMAs
+    const f4 p0 = lds_read16(a12 + 2 * i), p1 = lds_read16(a12 + 2 * i + 4);
+    const f4 p2 = lds_read16(a12 + 2 * i + 8), p3 = lds_read16(a12 + 2 * i + 12);
+    const f4 b0 = lds_read16(bk + i), b1 = lds_read16(bk + i + 4), b2 = lds_read16(bk + i + 8);
+    const float bb[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+    const f2 aa[8] = {f2{p0.x, p0.y}, f2{p0.z, p0.w}, f2{p1.x, p1.y}, f2{p1.z, p1.w},
+                      f2{p2.x, p2.y}, f2{p2.z, p2.w}, f2{p3.x, p3.y}, f2{p3.z, p3.w}};
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] = __builtin_elementwise_fma(aa[w], f2{bb[w + q], bb[w + q]}, c[q]);
+  }
+  for (; i < d4; i += 4) {
     const f4 p0 = lds_read16(a12 + 2 * i);
     const f4 p1 = lds_read16(a12 + 2 * i + 4);
     const f4 b0 = lds_read16(bk + i);
