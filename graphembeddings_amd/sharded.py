@@ -82,6 +82,13 @@ class SegmentItems:
 MAX_ITEM = 32   # source rows per work item; longer segments are split and combined atomically
 
 
+def _seg_of(starts: torch.Tensor, n: int) -> torch.Tensor:
+    """Segment index of each of n consecutive elements, given the segments' (nondecreasing, exclusive)
+    start offsets -- what repeat_interleave(arange, lengths) returns, by one binary search per element
+    (empty segments are skipped correctly: the LAST segment starting at or before the element wins)."""
+    return torch.searchsorted(starts, torch.arange(n, device=starts.device), right=True) - 1
+
+
 def segment_items(cnt: torch.Tensor, seg_bounds: torch.Tensor, seg_row: torch.Tensor, order: torch.Tensor) -> SegmentItems:
     """Cut segments (cnt[i] consecutive elements of `order` each, ordered by step) into work items of
     <= MAX_ITEM elements.  seg_bounds [S+1]: index of each step's first segment (and the total);
@@ -96,8 +103,9 @@ def segment_items(cnt: torch.Tensor, seg_bounds: torch.Tensor, seg_row: torch.Te
     host = torch.stack([torch.cat([zero, cum_it])[seg_bounds], torch.cat([zero, cum_sp])[seg_bounds]]).cpu()
     n_items, n_split = int(host[0, -1]), int(host[1, -1])
     seg_off = torch.cumsum(cnt, 0) - cnt
-    item_seg = torch.repeat_interleave(torch.arange(n_seg, device=dev), n_it, output_size=n_items)
-    r = torch.arange(n_items, device=dev) - (cum_it - n_it)[item_seg]
+    it_start = cum_it - n_it
+    item_seg = _seg_of(it_start, n_items)
+    r = torch.arange(n_items, device=dev) - it_start[item_seg]
     begin = seg_off[item_seg] + r * MAX_ITEM
     length = torch.clamp(cnt[item_seg] - r * MAX_ITEM, max=MAX_ITEM)
     row = seg_row[item_seg]
@@ -118,7 +126,7 @@ def _regroup(n: int, counts_src_major: torch.Tensor) -> torch.Tensor:
     src_start = torch.cumsum(flat, 0) - flat
     tflat = counts_src_major.t().reshape(-1)
     dst_start = (torch.cumsum(tflat, 0) - tflat).view(Bn, A).t().reshape(-1)   # indexed by a*Bn + b
-    seg = torch.repeat_interleave(torch.arange(A * Bn, device=dev), flat, output_size=n)
+    seg = _seg_of(src_start, n)
     return dst_start[seg] + (torch.arange(n, device=dev) - src_start[seg])
 
 
@@ -191,7 +199,10 @@ class ShardedTrainer:
         idz = torch.where(valid, ids, torch.zeros_like(ids))            # invalid ids alias row 0; their slots stay empty
         step = torch.arange(S, device=dev).view(S, 1)
         key = ((step * G + idz % G) * N + idz).reshape(-1)              # sorts as (step, owner, id)
+        if S * G * N < 2 ** 31:
+            key = key.to(torch.int32)                                   # 4 radix passes instead of 8
         key_sorted, perm = torch.sort(key)
+        key_sorted = key_sorted.to(torch.int64)
         uniq, seg_sorted, cnt = torch.unique_consecutive(key_sorted, return_inverse=True, return_counts=True)
         U = int(uniq.numel())
         inverse = torch.empty_like(seg_sorted)
@@ -235,12 +246,12 @@ class ShardedTrainer:
         tr, X = f // 3, f % 3
         gslot = (tr % B) * 6 + (tr // B) * 3 + X
         seg_bounds = torch.cat([step_start, torch.full((1,), U, dtype=torch.int64, device=dev)])
-        u_step = torch.repeat_interleave(torch.arange(S, device=dev), seg_bounds[1:] - seg_bounds[:-1], output_size=U)
+        u_step = _seg_of(step_start, U)
         reduce_items = segment_items(cnt, seg_bounds, torch.arange(U, device=dev) - step_start[u_step],
                                      gslot[perm % M6])
         # owner-apply items: the received gradient rows (one per requested (peer,row)) per shard row
         rows_local = int(self.shard.shape[0])
-        req_step = torch.repeat_interleave(torch.arange(S, device=dev), per_step_req, output_size=n_req)
+        req_step = _seg_of(req_start_dev, n_req)
         key4 = req_step * rows_local + req_all.to(torch.int64)
         if G > 1:
             key4_sorted, o2 = torch.sort(key4)
