@@ -165,6 +165,11 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * a row-sorted gradient-slot index for 32 steps at a time are built by one LDS bitonic-sort launch;
  * the update then touches every distinct row once, without atomics unless a row has > 16
  * occurrences); with only ge_hinge_step_workspace_bytes the loop falls back to sampler + atomics.
+ * The prepared path is the ONE place where the library keeps state behind the caller's back: per device
+ * a non-blocking side stream and four events (created on first use, never freed), on which the prepare
+ * launches for steps s+32.. run while `stream` executes steps s..; the two streams are ordered by events
+ * only, the host is never blocked.  Calls on the same device from several host threads must be
+ * serialised by the caller (as with the reference's init.so, init.cpp:145-150).
  * neg_ws: device [B,3] int32 scratch (holds the last step's negatives on return).  loss: device [n_steps*B] when keep_all_losses, else [B]
  * (last step).  model: 0 ComplEx, 1 HolE.
  * ev_pairs (nullable, HOST array of 2*n_steps events from ge_event_create): events are recorded on
