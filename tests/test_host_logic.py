@@ -58,3 +58,41 @@ def test_confidence_gate(capsys):
     assert r == [] and f == []                            # min_loss 0.3 >= threshold: not confident (holE.py:438)
     E.eval_link_prediction(zip(np.array([[0.4], [0.01]]), triples), {}, true, test, 1, r, f, infer_threshold=0.05)
     assert r == [1] and f == [1]
+
+
+def test_sharded_planner_index_helpers():
+    """_seg_of == repeat_interleave(arange, lengths) incl. empty segments; _regroup is a segmented transpose."""
+    import torch
+    from graphembeddings_amd import sharded as S
+    g = torch.Generator().manual_seed(0)
+    for _ in range(20):
+        lens = torch.randint(0, 5, (int(torch.randint(1, 30, (1,), generator=g)),), generator=g)
+        n = int(lens.sum())
+        starts = torch.cumsum(lens, 0) - lens
+        exp = torch.repeat_interleave(torch.arange(len(lens)), lens)
+        assert torch.equal(S._seg_of(starts, n), exp)
+    counts = torch.randint(0, 4, (5, 3), generator=g)          # segments (a, b) a-major
+    n = int(counts.sum())
+    seg = torch.repeat_interleave(torch.arange(15), counts.reshape(-1))
+    a, b = seg // 3, seg % 3
+    within = torch.arange(n) - (torch.cumsum(counts.reshape(-1), 0) - counts.reshape(-1))[seg]
+    dest = S._regroup(n, counts)
+    assert sorted(dest.tolist()) == list(range(n))
+    out = torch.empty(n, 3, dtype=torch.int64)
+    out[dest] = torch.stack([b, a, within], 1)                   # b-major order must be sorted by (b, a, within)
+    assert out.tolist() == sorted(out.tolist())
+
+
+def test_segment_items_cuts_long_segments():
+    import torch
+    from graphembeddings_amd import sharded as S
+    cnt = torch.tensor([1, 70, 3, 32, 33])
+    bounds = torch.tensor([0, 2, 5])                             # step 0: segments 0-1, step 1: segments 2-4
+    rows = torch.tensor([7, 8, 0, 1, 2])
+    order = torch.arange(int(cnt.sum()))
+    it = S.segment_items(cnt, bounds, rows, order)
+    assert it.item_start == [0, 4, 8] and it.split_start == [0, 1, 2]
+    assert it.length.tolist() == [1, 32, 32, 6, 3, 32, 32, 1]
+    assert it.begin.tolist() == [0, 1, 33, 65, 71, 74, 106, 138]
+    assert it.target.tolist() == [7, -9, -9, -9, 0, 1, -3, -3]  # split rows are encoded as ~row
+    assert it.split_rows.tolist() == [8, 2]
