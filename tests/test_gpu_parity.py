@@ -424,6 +424,30 @@ def test_train_steps_fast_path_is_reproducible(H):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_train_steps_soak_across_prepare_chunks(H):
+    """200 steps = 7 look-ahead prepare launches (32 steps each, two recycled buffers, side stream):
+    two runs are bitwise identical, and splitting the run at arbitrary points (70 + 1 + 129 steps, i.e.
+    re-entering ge_train_steps mid-chunk) changes nothing."""
+    rng = np.random.default_rng(1)
+    N, d, B, T = 30000, 200, 1024, 50000
+    tri = np.stack([rng.integers(10, N, T), rng.integers(10, N, T), rng.integers(10, N, T)], 1).astype(np.int32)
+    tt = H.TypeTables.from_host(np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32),
+                                padded_size=0)
+    base = dev((rng.standard_normal((N, d)) * 0.05).astype(np.float32))
+    outs, losses = [], []
+    for parts in ((200,), (200,), (70, 1, 129)):
+        emb = base.clone()
+        tr = H.Trainer(emb, dev(tri), tt, B, seed=5)
+        for n in parts:
+            last = tr.run(n)
+        torch.cuda.synchronize()
+        outs.append(emb)
+        losses.append(last.clone())
+    assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], base)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(losses[0], losses[2])
+
+
 # ---------------------------------------------------------------- Bernoulli filtered sampler (init.cpp)
 def test_bernoulli_sampler_bit_exact_vs_pinned_oracle(H):
     from oracle import transx_oracle as TO
