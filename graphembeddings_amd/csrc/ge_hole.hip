@@ -348,8 +348,21 @@ __global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kern
     HoleFwd fp, fn;
     // G[side][X]: X = 0 h, 1 t, 2 r
     float GP[3][NCH][4], GN[3][NCH][4];
+    // one pair per wave: make the ids scalar so the sharing tests below are scalar branches
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { p[c] = __builtin_amdgcn_readfirstlane(p[c]); n[c] = __builtin_amdgcn_readfirstlane(n[c]); }
     hole_forward<NCH, true>(rows, d, d4, p, lds, lane, max_norm, fp, GP[2], GP[0]);
-    hole_forward<NCH, true>(rows, d, d4, n, lds, lane, max_norm, fn, GN[2], GN[0]);
+    // pos and neg differ in one entity, so one of the six correlations is shared (bitwise the same sum):
+    // head corrupted -> (r star t) is common, tail corrupted -> (rev r star h) is common.
+    if (n[1] == p[1] && n[2] == p[2]) {
+      hole_forward<NCH, false>(rows, d, d4, n, lds, lane, max_norm, fn, GN[2], GN[0]);   // only (h' star t)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) GN[0][c][q] = GP[0][c][q];
+    } else {
+      hole_forward<NCH, true>(rows, d, d4, n, lds, lane, max_norm, fn, GN[2], GN[0]);
+    }
     const float pre = fp.sig - fn.sig + margin;
     const bool on = live && !bad && (pre >= 0.f);
     if (live && lane == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
@@ -358,7 +371,14 @@ __global__ __launch_bounds__(kBlock, NCH == 1 ? 4 : 2) void hole_hinge_grad_kern
       continue;
     }
     hole_backward_t<NCH>(rows, d, d4, p, lds, lane, GP[1]);
-    hole_backward_t<NCH>(rows, d, d4, n, lds, lane, GN[1]);
+    if (n[0] == p[0] && n[2] == p[2]) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) GN[1][c][q] = GP[1][c][q];
+    } else {
+      hole_backward_t<NCH>(rows, d, d4, n, lds, lane, GN[1]);
+    }
     const float cp = fp.sig * (1.f - fp.sig), cn = -fn.sig * (1.f - fn.sig);
 #pragma unroll
     for (int X = 0; X < 3; ++X) {
