@@ -246,6 +246,32 @@ def test_step_matches_torch_eager_fp32_on_device(H):
     assert (ours - ref).abs().max().item() < TABLE_TOL
 
 
+def test_hole_step_matches_torch_fft_autograd_on_device(H):
+    """HolE: README.md:42's FFT formula (ifft(conj(fft(h)) fft(t)), score r.(h star t)) evaluated with torch.fft
+    (rocFFT) and differentiated by autograd on the device == the direct-correlation kernels, loss and table."""
+    rng = np.random.default_rng(8)
+    N, d, B = 3000, 200, 1024
+    table = (rng.standard_normal((N, d)) * rng.uniform(0.02, 0.12, (N, 1))).astype(np.float32)   # norms 0.3 .. 1.7
+    pos = np.stack([rng.integers(20, N, B), rng.integers(20, N, B), rng.integers(0, 20, B)], 1).astype(np.int32)
+    neg = pos.copy()
+    neg[: B // 2, 0] = rng.integers(20, N, B // 2)             # head-corrupted half, tail-corrupted half
+    neg[B // 2:, 1] = rng.integers(20, N, B - B // 2)
+    ours, ref = dev(table).clone(), dev(table).clone()
+    loss = H.HingeSGD(ours, B, margin=0.2, model="hole").step(dev(pos), dev(neg), 0.1)[:, 0]
+    idx = torch.cat([dev(pos), dev(neg)], 0).long()
+    rows = [ref[idx[:, c]].detach().requires_grad_(True) for c in range(3)]
+    h, t, r = [x * torch.clamp(torch.rsqrt((x * x).sum(1, keepdim=True)), max=1.0) for x in rows]
+    corr = torch.fft.irfft(torch.conj(torch.fft.rfft(h, dim=1)) * torch.fft.rfft(t, dim=1), n=d, dim=1)
+    e = torch.sigmoid((r * corr).sum(1))
+    ref_loss = torch.clamp(e[:B] - e[B:] + 0.2, min=0.0)
+    ref_loss.sum().backward()
+    with torch.no_grad():
+        for c in range(3):
+            ref.index_add_(0, idx[:, c], rows[c].grad, alpha=-0.1)
+    assert (loss - ref_loss.detach()).abs().max().item() < SCORE_TOL
+    assert (ours - ref).abs().max().item() < 2e-5
+
+
 def test_step_is_linear_in_duplicated_pairs(H, G):
     # ScatterSub applies every occurrence: a batch holding each pair twice moves the table twice as far
     t0 = dev(G["d200_table"])
