@@ -295,11 +295,30 @@ size_t hinge_ws_bytes(int64_t B, int32_t d) {
 
 bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= kFastMaxB && d <= 1024; }
 
-// training workspace: [gidx 6B][gval 6B x gs][partials 4B x gs][prep buffer 0][prep buffer 1],
-// gs = gradient-row stride padded to whole 128-byte lines (the fused kernel's publish unit)
+// training workspace: [gidx 6B][gval RING x (6B x gs)][partials 4B x gs][prep buffer 0][prep buffer 1],
+// gs = gradient-row stride padded to whole 128-byte lines (the fused kernel's publish unit).
+// The gradient rows go to a RING of regions, one per step in turn: a region is written by the grad kernel
+// on one XCD and read by the apply kernel on another, and rewriting lines that still sit in another XCD's
+// L2 costs ~3.7 us per 13 MB (tools/xcd_locality_probe.hip: 9.1 vs 5.4 us); by the time a region comes
+// round again (normally 4 steps later, > the 32 MB of L2 in between) its lines have been evicted and the
+// stores take the fast path.
+static size_t grad_region_bytes(int64_t B, int32_t d) {
+  return align_up_sz(sizeof(float) * 6 * (size_t)B * (size_t)fused_gstride(d), 256);
+}
+static int grad_ring(int64_t B, int32_t d) {
+  const size_t reg = grad_region_bytes(B, d);
+  if (const char* e = getenv("GE_GRAD_RING")) { const int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning
+  // measured at B=4096, d=200 (22 MB regions): 1 -> 22.4, 2 -> 21.3, 4 -> 21.0, 8 -> 21.0, 16 -> 21.8, 32 -> 22.8 us/step:
+  // long enough to outlive the L2s, short enough to stay inside the 256 MB Infinity Cache
+  size_t r = ((size_t)64 << 20) / reg + 1;
+  if (r < 2) r = 2;
+  if (r > 16) r = 16;
+  if (r < 4 && 4 * reg <= ((size_t)160 << 20)) r = 4;
+  return (int)r;
+}
 static size_t train_grad_bytes(int64_t B, int32_t d) {
   const size_t gs = (size_t)fused_gstride(d);
-  return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + align_up_sz(sizeof(float) * 6 * (size_t)B * gs, 256) +
+  return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + (size_t)grad_ring(B, d) * grad_region_bytes(B, d) +
          align_up_sz(sizeof(float) * 4 * (size_t)B * gs, 256);
 }
 size_t train_ws_bytes(int64_t B, int32_t d) {
@@ -360,10 +379,12 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
                     int32_t* neg_ws, void* workspace, size_t workspace_bytes, void** ev_pairs, int ev_kernel,
                     hipStream_t st) {
   int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
-  float* gval = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256));
+  float* gval0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256));
   const bool fast = train_fast_ok(B, d) && workspace_bytes >= train_ws_bytes(B, d);
   const size_t grow = (size_t)fused_gstride(d);  // floats per gradient row in the fused layout
-  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(gval) + align_up_sz(sizeof(float) * 6 * (size_t)B * grow, 256));
+  const int ring = fast ? grad_ring(B, d) : 1;
+  const size_t region_floats = grad_region_bytes(B, d) / sizeof(float);
+  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(gval0) + (size_t)ring * grad_region_bytes(B, d));
   int32_t* prep_base = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + train_grad_bytes(B, d));
   int lpt_, niter_;
   const bool fused = fast && model == 0 && fused_enabled() && fused_shape_ok(d, table, lpt_, niter_);
@@ -430,6 +451,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
       neg = neg_ws;
     }
     if (e1 && ev_kernel == 0) (void)hipEventRecord(e1, st);
+    float* gval = gval0 + (size_t)(gs % (uint64_t)ring) * region_floats;   // this step's region of the ring
     // the timing events ride on the dispatch packet itself (hipExtLaunchKernel start/stop events):
     // they report the kernel's own begin/end timestamps, like rocprofv3's kernel trace
     hipEvent_t g0 = ev_kernel == 1 ? e0 : nullptr, g1 = ev_kernel == 1 ? e1 : nullptr;

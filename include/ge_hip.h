@@ -161,7 +161,8 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * ge_corrupt_batch with step = global_step0 + s; lr_s = lr0 / (1 + decay_rate * (global_step0+s) /
  * decay_steps) (tf.train.inverse_time_decay, holE.py:292-294; decay_steps <= 0 keeps lr0); then one
  * ge_*_hinge_step.  No host synchronisation; every launch goes to `stream` in order.
- * workspace: >= ge_train_workspace_bytes(B, d) enables the prepared path for B <= 4096 (negatives and
+ * workspace: >= ge_train_workspace_bytes(B, d) (it holds a ring of gradient-row regions, one per step in turn,
+ * so that a region is not rewritten while its lines still sit in another XCD's L2) enables the prepared path for B <= 4096 (negatives and
  * a row-sorted gradient-slot index for 32 steps at a time are built by one LDS bitonic-sort launch;
  * the update then touches every distinct row once, without atomics unless a row has > 16
  * occurrences); with only ge_hinge_step_workspace_bytes the loop falls back to sampler + atomics.

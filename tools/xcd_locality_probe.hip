@@ -39,5 +39,22 @@ int main() {
     }
     printf("%s shift %4d: writer %.2f us, reader %.2f us\n", nt ? "nontemporal reads" : "plain reads      ", shift, tw / reps * 1e3, tr / reps * 1e3);
   }
+  // Ring experiment: the pair (writer, reader with shift 1) walks a ring of R regions of 13.1 MB, so a region is
+  // rewritten only every R iterations -- does the extra cost of rewriting lines last read on another XCD age out?
+  for (int R : {1, 4, 16, 64}) {
+    float4* ring; CK(hipMalloc(&ring, (size_t)R * grid * per_block * 16));
+    CK(hipMemset(ring, 0, (size_t)R * grid * per_block * 16));
+    float tw = 0, tr = 0; const int reps = 256;
+    for (int r = 0; r < reps + 64; ++r) {
+      float4* reg = ring + (size_t)(r % R) * grid * per_block;
+      hipExtLaunchKernelGGL(writer, dim3(grid), dim3(256), 0, 0, e0, e1, 0, reg, per_block, (float)r);
+      hipExtLaunchKernelGGL(reader<false>, dim3(grid), dim3(256), 0, 0, e2, e3, 0, (const f4v*)reg, per_block, 1, out);
+      CK(hipEventSynchronize(e3));
+      float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e2, e3));
+      if (r >= 64) { tw += a; tr += b; }
+    }
+    printf("ring of %2d regions (%4.0f MB), shift 1: writer %.2f us, reader %.2f us\n", R, R * 13.1, tw / reps * 1e3, tr / reps * 1e3);
+    CK(hipFree(ring));
+  }
   return 0;
 }
