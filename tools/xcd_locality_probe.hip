@@ -21,6 +21,18 @@ __global__ void __launch_bounds__(256) reader(const f4v* buf, int per_block, int
   }
   if (acc == -1.f) out[0] = acc;
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// reader whose loads carry sc1 (aux bit 4): served past this XCD's L2
+__global__ void __launch_bounds__(256) reader_sc1(const float4* buf, int per_block, int shift, float* out, int total_bytes) {
+  const int src = (blockIdx.x + shift) % gridDim.x;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, total_bytes, 0x00020000);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < per_block; i += 256) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(((size_t)src * per_block + i) * 16), 0, 16);
+    acc += __uint_as_float(u.x) + __uint_as_float(u.y);
+  }
+  if (acc == -1.f) out[0] = acc;
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main() {
   const int grid = 2048, per_block = 400;            // 400 float4 = 6.4 KB per workgroup, 13.1 MB in all
@@ -38,6 +50,18 @@ int main() {
       if (r >= 10) { tw += a; tr += b; }
     }
     printf("%s shift %4d: writer %.2f us, reader %.2f us\n", nt ? "nontemporal reads" : "plain reads      ", shift, tw / reps * 1e3, tr / reps * 1e3);
+  }
+  // sc1 loads in the reader (shift 1): do they leave the writer on the fast path?
+  {
+    float tw = 0, tr = 0; const int reps = 200;
+    for (int r = 0; r < reps + 10; ++r) {
+      hipExtLaunchKernelGGL(writer, dim3(grid), dim3(256), 0, 0, e0, e1, 0, buf, per_block, (float)r);
+      hipExtLaunchKernelGGL(reader_sc1, dim3(grid), dim3(256), 0, 0, e2, e3, 0, (const float4*)buf, per_block, 1, out, grid * per_block * 16);
+      CK(hipEventSynchronize(e3));
+      float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e2, e3));
+      if (r >= 10) { tw += a; tr += b; }
+    }
+    printf("sc1 reads         shift    1: writer %.2f us, reader %.2f us\n", tw / reps * 1e3, tr / reps * 1e3);
   }
   // Ring experiment: the pair (writer, reader with shift 1) walks a ring of R regions of 13.1 MB, so a region is
   // rewritten only every R iterations -- does the extra cost of rewriting lines last read on another XCD age out?
