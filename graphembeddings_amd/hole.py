@@ -166,12 +166,19 @@ class HingeSGD:
         self.margin, self.max_norm = float(margin), float(max_norm)
         self.model = _MODELS[model]
         self._ws = None
+        self._turn = 0
         self._reserve(batch_size)
 
+    # The gradient rows are written by one kernel and read by the next on other XCDs; rewriting a buffer whose
+    # lines still sit in another XCD's L2 is the slow path (profiles/r01_xcd_locality_probe.txt), so small
+    # workspaces are rotated (4 regions, the same trick as ge_train_steps); large ones evict themselves.
+    _RING, _RING_MAX_BYTES = 4, 48 << 20
+
     def _reserve(self, B: int):
-        need = _lib.load().ge_hinge_step_workspace_bytes(B, self.embeddings.shape[1])
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.embeddings.device)
+        need = max(_lib.load().ge_hinge_step_workspace_bytes(B, self.embeddings.shape[1]), 256)
+        if self._ws is None or self._ws.shape[1] < need:
+            ring = self._RING if need <= self._RING_MAX_BYTES else 1
+            self._ws = torch.empty(ring, (need + 255) // 256 * 256, dtype=torch.uint8, device=self.embeddings.device)
 
     def step(self, pos: torch.Tensor, neg: torch.Tensor, lr: float) -> torch.Tensor:
         """One training step in place on the table; returns the per-pair hinge [B,1]."""
@@ -183,9 +190,11 @@ class HingeSGD:
         self._reserve(B)
         loss = torch.empty(B, dtype=torch.float32, device=emb.device)
         fn = "ge_complex_hinge_step" if self.model == MODEL_COMPLEX else "ge_hole_hinge_step"
+        ws = self._ws[self._turn % self._ws.shape[0]]
+        self._turn += 1
         _lib.call(fn, emb.data_ptr(), emb.shape[0], emb.shape[1], p.data_ptr(), n.data_ptr(), B,
-                  self.margin, float(lr), self.max_norm, loss.data_ptr(), self._ws.data_ptr(),
-                  self._ws.numel(), _stream())
+                  self.margin, float(lr), self.max_norm, loss.data_ptr(), ws.data_ptr(),
+                  ws.numel(), _stream())
         return loss.view(-1, 1)
 
 
