@@ -63,6 +63,19 @@ int main() {
     }
     printf("sc1 reads         shift    1: writer %.2f us, reader %.2f us\n", tw / reps * 1e3, tr / reps * 1e3);
   }
+  // Table-like pattern: EVERY XCD reads the whole buffer (8 passes with shifts 0..7), then it is rewritten.
+  {
+    float tw = 0; const int reps = 100;
+    for (int r = 0; r < reps + 10; ++r) {
+      hipExtLaunchKernelGGL(writer, dim3(grid), dim3(256), 0, 0, e0, e1, 0, buf, per_block, (float)r);
+      for (int sh = 0; sh < 8; ++sh)
+        hipLaunchKernelGGL(reader<false>, dim3(grid), dim3(256), 0, 0, (const f4v*)buf, per_block, sh, out);
+      CK(hipDeviceSynchronize());
+      float a; CK(hipEventElapsedTime(&a, e0, e1));
+      if (r >= 10) tw += a;
+    }
+    printf("read by all 8 XCDs, then rewritten: writer %.2f us\n", tw / reps * 1e3);
+  }
   // Ring experiment: the pair (writer, reader with shift 1) walks a ring of R regions of 13.1 MB, so a region is
   // rewritten only every R iterations -- does the extra cost of rewriting lines last read on another XCD age out?
   for (int R : {1, 4, 16, 64}) {
