@@ -203,9 +203,25 @@ def run_single(args):
     if args.model == "hole":
         kernel_names[1] = "hole_hinge_grad_kernel"
 
-    # timed region: exactly K steps; HIP events (on the launch stream) bracket the dominant kernel of
-    # every 4th step -- every step would add two barrier packets per step and perturb `value`
-    EVERY = 4
+    # timed region.  One "call" = one ge_train_steps call of exactly K steps, as the driver asks; the
+    # call is repeated back to back until the region is >= MIN_TIMED_MS long, because K=20 steps are
+    # 0.4 ms -- too short for a stable wall-clock figure.  `value` is the steady state over those calls
+    # (each call continues the sequence, so its prepared records were built ahead on the side stream);
+    # `cold_call` is ONE K-step call right after a pipeline reset, with its first prepare launch exposed.
+    # HIP events ride on the dominant kernel's dispatch in every 4th step of the first call only --
+    # every step would add two barrier packets per step and perturb `value`.
+    MIN_TIMED_MS, EVERY = 5.0, 4
+    tr.invalidate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.run(K)
+    torch.cuda.synchronize()
+    cold_el = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tr.run(K)
+    torch.cuda.synchronize()
+    est = max(time.perf_counter() - t0, 1e-6)
+    reps = max(1, int(np.ceil(MIN_TIMED_MS * 1e-3 / est)))
     ev = H.Events(2 * ((K + EVERY - 1) // EVERY))
     handles = []
     for i in range(K):
@@ -213,8 +229,10 @@ def run_single(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr.run(K, events=handles, ev_kernel=dom)
+    for _ in range(reps - 1):
+        tr.run(K)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el = (time.perf_counter() - t0) / reps
     n_ev = len(ev.handles) // 2
     kern_ms = sum(ev.elapsed_ms(2 * i, 2 * i + 1) for i in range(n_ev)) / n_ev
     ev.close()
@@ -229,6 +247,9 @@ def run_single(args):
     out = {
         "metric": "scored triples/sec/GPU (d=200)", "value": value, "unit": "scored triples/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
+        "timed_calls": reps, "timed_ms": el * reps * 1e3,
+        "cold_call": {"value": 2.0 * B * K / cold_el, "ms_per_step": cold_el / K * 1e3,
+                      "note": "one K-step call right after a pipeline reset (first prepare launch exposed)"},
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": name, "batch_per_gpu": B, "embedding_dim": d, "table_rows": int(n_rows),
                    "table_mb": round(n_rows * d * 4 / 1e6, 1), "parallelism": "1 GPU",

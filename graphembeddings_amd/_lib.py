@@ -36,9 +36,14 @@ SYMBOLS = {
     "ge_bernoulli_corrupt_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _u64, _u64, _p, _p]),
     "ge_complex_score_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _f, C.c_int, C.c_int, _p, _p]),
     "ge_train_workspace_bytes": (_sz, [_i64, _i32]),
-    "ge_set_fused_step": (C.c_int, [C.c_int]),
+    "ge_train_pipeline_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ge_train_pipeline_reset": (C.c_int, [_p]),
+    "ge_train_pipeline_destroy": (C.c_int, [_p]),
     "ge_train_steps": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _i64, _i64, _p, _p, _i32, _p, _u64, _u64, _i32,
-                                 _i32, _f, _f, _f, _f, _f, C.c_int, _p, C.c_int, _p, _p, _sz, _p, C.c_int, _p]),
+                                 _i32, _f, _f, _f, _f, _f, C.c_int, _p, C.c_int, _p, _p, _sz, _p, C.c_int, _p, _p]),
+    "ge_train_prepared_layout": (C.c_int, [_i64, C.POINTER(C.c_int64)]),
+    "ge_train_prepare_steps": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _u64, _u64, _i32, _i32,
+                                         C.c_int, _p, _sz, _p]),
     "ge_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ge_event_destroy": (C.c_int, [_p]),
     "ge_event_record": (C.c_int, [_p, _p]),
@@ -82,7 +87,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and the header diverge
             fn.restype = res
             fn.argtypes = args
-        if lib.ge_version() < 100:
+        if lib.ge_version() < 200:
             raise RuntimeError("libge_hip.so is older than the Python host expects")
         _lib = lib
     return _lib

@@ -13,7 +13,6 @@
 // wave TM x TN tiles of 32x32; k is walked in chunks of 16 complex dims (= 32 real k) staged in LDS
 // with a row stride of 33 floats so the 32 rows a half-wave reads per operand fall in 32 banks.
 #include "ge_common.h"
-#include <cstdlib>
 
 namespace ge {
 
@@ -320,16 +319,14 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
   dim3 grid((unsigned)gx, (unsigned)gy);
   const int KP = (k + 3) & ~3;
   const size_t fullk_lds = sizeof(float) * (size_t)(2 * 64 * (2 * KP + 1) + 128);
-  if (!big && fullk_lds <= 150 * 1024 && !getenv("GE_1VK_CHUNKED")) {
-    static bool attr[2] = {false, false};
-    if (!attr[v4]) {
-      hipError_t e = v4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_fullk_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                        : hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_fullk_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr[v4] = true;
-    }
+  if (!big && fullk_lds <= 150 * 1024) {
+    // the opt-in is a per-device property: set it on every launch (idempotent, cheap) rather than cache a
+    // per-process flag that would be wrong on a second device
+    hipError_t e = v4 ? hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_fullk_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                      : hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_fullk_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
     if (v4)
       hipLaunchKernelGGL(score_1vK_fullk_kernel<true>, grid, dim3(kBlock), fullk_lds, st, table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out, KP);
     else

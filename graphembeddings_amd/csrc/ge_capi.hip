@@ -6,7 +6,7 @@
 namespace ge {
 int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
 int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr);
 int complex_max_dim();
 int hole_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
 int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
@@ -23,8 +23,12 @@ int table_sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int table_scale_launch(float*, int64_t, float, hipStream_t);
 size_t hinge_ws_bytes(int64_t, int32_t);
 size_t train_ws_bytes(int64_t, int32_t);
-int set_fused_step(int);
-int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, hipStream_t);
+int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, void*, hipStream_t);
+int train_prepare_run(const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int, int32_t*, hipStream_t);
+void train_prepared_layout(int64_t, int64_t*);
+int pipeline_create(void**);
+int pipeline_reset(void*);
+int pipeline_destroy(void*);
 }  // namespace ge
 
 using namespace ge;
@@ -169,7 +173,7 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
                    int32_t padded_size, int32_t mode, float margin, float lr0, float decay_steps,
                    float decay_rate, float max_norm, int model, float* loss, int keep_all_losses,
                    int32_t* neg_ws, void* workspace, size_t workspace_bytes, void** ev_pairs, int ev_kernel,
-                   void* stream) {
+                   void* pipeline, void* stream) {
   if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm))
     return GE_EINVAL;
   if (!triples || !id_to_type || !type_offsets || !type_ids || !loss || !neg_ws || !workspace) return GE_EINVAL;
@@ -181,10 +185,32 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
   return train_steps_run(table, N, d, triples, T, first_row, B, n_steps, id_to_type, type_offsets, n_types,
                          type_ids, seed, global_step0, padded_size, mode, margin, lr0, decay_steps, decay_rate,
                          max_norm, model, loss, keep_all_losses, neg_ws, workspace, workspace_bytes, ev_pairs,
-                         ev_kernel, (hipStream_t)stream);
+                         ev_kernel, pipeline, (hipStream_t)stream);
 }
 
-int ge_set_fused_step(int on) { return set_fused_step(on); }
+int ge_train_pipeline_create(void** pipeline) { return pipeline ? pipeline_create(pipeline) : GE_EINVAL; }
+int ge_train_pipeline_reset(void* pipeline) { return pipeline_reset(pipeline); }
+int ge_train_pipeline_destroy(void* pipeline) { return pipeline_destroy(pipeline); }
+
+int ge_train_prepared_layout(int64_t B, int64_t* out8) {
+  if (B <= 0 || !out8) return GE_EINVAL;
+  train_prepared_layout(B, out8);
+  return 0;
+}
+
+int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t n_steps,
+                           const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
+                           const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
+                           int32_t mode, int direct, int32_t* out, size_t out_bytes, void* stream) {
+  if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || N <= 0) return GE_EINVAL;
+  if (!triples || !id_to_type || !type_offsets || !type_ids || !out) return GE_EINVAL;
+  if (mode < 0 || mode > 3 || padded_size < 0 || n_types < 0) return GE_EINVAL;
+  int64_t lay[8];
+  train_prepared_layout(B, lay);
+  if (out_bytes < sizeof(int32_t) * (size_t)n_steps * (size_t)lay[0]) return GE_ENOMEM;
+  return train_prepare_run(triples, T, first_row, B, n_steps, id_to_type, N, type_offsets, n_types, type_ids, seed,
+                           global_step0, padded_size, mode, direct, out, (hipStream_t)stream);
+}
 
 // workspace: [sumsq: 256 B][grad_idx: 3M int32, 256-B padded][grad_val: 3M*d fp32]
 size_t ge_logloss_step_workspace_bytes(int64_t M, int32_t d) {

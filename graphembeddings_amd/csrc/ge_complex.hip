@@ -16,7 +16,6 @@
 // identity for a trilinear form, (d s/d y_X) . x_X = s / scale_X: the backward pass through the
 // clip needs no reduction beyond the forward ones.
 #include "ge_complex_dev.h"
-#include <cstdlib>
 
 namespace ge {
 
@@ -91,13 +90,14 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
 template <int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
-    const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ pos,
+    const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
-    const int32_t* __restrict__ slot_item) {
-  // slot_item (training loop only, else null): a slot tagged kSlotDirect is the ONLY gradient slot
-  // of its table row in this step -- this pair is the row's only reader and writer -- so the update is
-  // applied right here (rows + (-lr*g)) and no gradient row is written for it.
+    const int32_t* __restrict__ slot_item, float* table_rw) {
+  // slot_item + table_rw (training loop only, else null; table_rw aliases `rows`, which is therefore
+  // NOT declared __restrict__ const in that instantiation): a slot tagged kSlotDirect is the ONLY
+  // gradient slot of its table row in this step -- this pair is the row's only reader and writer -- so
+  // the update is applied right here (rows + (-lr*g)) and no gradient row is written for it.
   constexpr int kSlotDirect = -2;
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
@@ -105,7 +105,6 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int k = d >> 1, nvec = k / VEC;
   const float neg_lr = -lr;
-  float* const table_rw = const_cast<float*>(rows);
   for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
     const int64_t g = base + grp;
     const bool live = g < B;
@@ -276,10 +275,6 @@ static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
   const int nvec = k / vec;
   int lpt = 16;
   while (lpt < 64 && lpt < nvec) lpt <<= 1;
-  if (const char* e = getenv("GE_LPT")) {   // tuning override: lanes per triple (power of two >= default)
-    const int v = atoi(e);
-    if (v == 16 || v == 32 || v == 64) lpt = v;
-  }
   int niter = (nvec + lpt - 1) / lpt;
   if (niter > 2) niter = 4;
   if (niter > max_niter) return false;
@@ -341,16 +336,17 @@ int complex_hinge_loss_launch(const float* table, int64_t N, int32_t d, const in
 int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos,
                               const int32_t* neg, int64_t B, float margin, float lr, float max_norm,
                               float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st,
-                              hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* slot_item) {
+                              hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* slot_item, float* table_rw) {
   Shape s;
   if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   // the gradient rows are written with the same vector width: grad_val must be as aligned as rows
   while (s.vec > 1 && (reinterpret_cast<uintptr_t>(grad_val) % (s.vec * 4)) != 0) return GE_EINVAL;
+  if ((slot_item != nullptr) != (table_rw != nullptr)) return GE_EINVAL;
   if (B == 0) return 0;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item)
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw)
   GE_DISPATCH_SHAPE(s, 2, CALL);
 #undef CALL
   return launch_status();

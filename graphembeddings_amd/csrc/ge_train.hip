@@ -3,11 +3,12 @@
 // Negatives depend only on (seed, step, positives) -- never on the table -- so everything about a
 // step except its floating-point work can be prepared ahead, in bulk, for a chunk of steps:
 //
-//   train_prepare_kernel   one 1024-thread workgroup per step: draws the step's negatives
-//                          (holE.py:97-140, 343-347), builds the (row, IndexedSlices slot) list of the
-//                          <= 4B gradient rows the step will emit, sorts it by row with a bitonic
-//                          sort held entirely in LDS (4B x 8 B = 128 KiB of the CU's 160 KiB at
-//                          B=4096) and cuts it into work items of <= C entries of one row.
+//   train_prepare_kernel   one 1024-thread workgroup per (step, sub-batch of <= 4096 pairs): draws the
+//                          negatives (holE.py:97-140, 343-347), builds the (row, IndexedSlices slot)
+//                          list of the <= 4 gradient rows per pair, sorts it by row with a stable LSD
+//                          radix sort held entirely in LDS (wave-level multisplit: ballot ranks +
+//                          per-wave digit counters, 2 passes for FB15k's 16,296 rows, 3 for 1.2 M rows)
+//                          and cuts it into work items of <= 16 slots of one row.
 //   (per step) hinge_grad  fused gather -> clip -> score -> sigmoid -> hinge -> gradient rows
 //   (per step) apply_sorted_kernel   one wavefront per work item sums its gradient rows and
 //                          updates the table row ONCE with a plain read-modify-write.
@@ -15,46 +16,30 @@
 // This replaces the float-atomic ScatterSub (memory-side atomics ~1.3 TB/s chip-wide and an order
 // of magnitude slower when many waves hit one hot row -- Zipfian heads, a handful of relations)
 // by coalesced row reads plus one write per distinct row, and makes the update order fixed:
-// rows with <= C occurrences (the vast majority) are bitwise reproducible.  Only rows split
-// over several work items combine their partial sums with atomics.
+// rows with <= 16 occurrences (the vast majority) are bitwise reproducible for B <= 4096.  Only rows
+// split over several work items (and, for B > 4096, rows shared by several sub-batches) combine their
+// partial sums with atomics.
+//
+// The prepared records live in the caller's workspace, two chunks of steps (double buffer).  With a
+// pipeline handle (ge_train_pipeline_create) the prepare launches run on the handle's side stream one
+// chunk AHEAD of the steps that consume them -- across ge_train_steps calls too: a call that continues
+// where the previous one stopped finds its records already built.  Without a handle the launches go
+// to the caller's stream (one ~20 us launch per chunk of steps) and the library keeps no state at all.
 #include "ge_common.h"
-#include <cstdlib>
 
 namespace ge {
 
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr);
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 
-struct FusedArgs {
-  const int32_t* slot_item; const int32_t* items; const int32_t* occ;
-  int32_t* item_cnt; int32_t* row_cnt; float* partials; int32_t* gidx; float* gval; int gstride; int debug;
-};
-bool fused_shape_ok(int d, const void* table, int& lpt, int& niter);
-int fused_gstride(int d);
-int complex_fused_step_launch(float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float,
-                              float*, const FusedArgs&, hipStream_t, hipEvent_t, hipEvent_t);
-
-static int g_fused_enabled = -1;  // -1: read GE_FUSED_STEP on first use
-int set_fused_step(int on) {
-  const int prev = g_fused_enabled;
-  g_fused_enabled = on ? 1 : 0;
-  return prev;
-}
-static bool fused_enabled() {
-  if (g_fused_enabled < 0) {
-    const char* e = getenv("GE_FUSED_STEP");
-    g_fused_enabled = (e && e[0] == '1') ? 1 : 0;   // opt-in: measured slower than the two-launch step
-  }
-  return g_fused_enabled == 1;
-}
-
 constexpr int kSlotDirect = -2;  // slot_item code: sole contributor of its row, applied by the producer
 constexpr int kPrepThreads = 1024;
+constexpr int kPrepWaves = kPrepThreads / kWave;
 constexpr int kItemCap = 16;       // C: max gradient rows summed by one wavefront
-constexpr int kPrepChunk = 32;     // steps prepared per launch (two buffers of 32 x ~1.7 MB at B=4096)
-constexpr int64_t kFastMaxB = 4096;  // 4B sort keys of 8 B must fit the CU's LDS
+constexpr int64_t kSub = 4096;     // pairs sorted by one workgroup: 4 x 4096 keys of 8 B = 128 KiB of the CU's 160 KiB
+constexpr int kMaxRadix = 256;
 
 __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_t B, int64_t s) {
   // batch s starts at first_row + s*B, wrapping to row 0 whenever a batch would run past T
@@ -67,164 +52,251 @@ __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_
   return ((s - n0) % per) * B;
 }
 
-// per-step int32 layout of the prepared data:
-//   neg[3B] occ[4B] items[4B*5] n_items[64] slot_item[6B] item_cnt[4B] row_cnt[4B] islots[4B*16]
-__host__ __device__ inline int64_t prep_stride(int64_t B) { return 105 * B + 64; }
-__host__ __device__ inline int64_t off_occ(int64_t B) { return 3 * B; }
-__host__ __device__ inline int64_t off_items(int64_t B) { return 7 * B; }
-__host__ __device__ inline int64_t off_nitems(int64_t B) { return 27 * B; }
-__host__ __device__ inline int64_t off_slot_item(int64_t B) { return 27 * B + 64; }
-__host__ __device__ inline int64_t off_item_cnt(int64_t B) { return 33 * B + 64; }
-__host__ __device__ inline int64_t off_row_cnt(int64_t B) { return 37 * B + 64; }
-__host__ __device__ inline int64_t off_islots(int64_t B) { return 41 * B + 64; }
+// ------------------------------------------------------------------ prepared-step record (int32 words)
+//   neg[3B] | slot_item[6B] | pad to 64 | n_sub x { n_items, pad to 64 | items[4*S][2] | islots[4*S][16] }
+// S = pairs per sub-batch (min(B, 4096) rounded up to 256).  items[k] = {table row, count | multi << 30};
+// islots[k][0..16) = the IndexedSlices slots (6*pair + {0 h+,1 t+,2 r+,3 h-,4 t-,5 r-}) the item sums, -1 padded.
+struct PrepLayout {
+  int64_t B, n_sub, S, P, off_slot, off_sub, sub_stride, off_items, off_islots, stride;
+};
+__host__ __device__ inline PrepLayout prep_layout(int64_t B) {
+  PrepLayout L;
+  L.B = B;
+  L.n_sub = (B + kSub - 1) / kSub;
+  const int64_t s = B < kSub ? B : kSub;
+  L.S = (s + 255) / 256 * 256;
+  L.P = 4 * L.S;                       // sort keys per workgroup, a multiple of 1024
+  L.off_slot = 3 * B;
+  L.off_sub = (9 * B + 63) / 64 * 64;
+  L.off_items = 64;
+  L.off_islots = 64 + 2 * L.P;
+  L.sub_stride = 64 + 2 * L.P + kItemCap * L.P;
+  L.stride = L.off_sub + L.n_sub * L.sub_stride;
+  return L;
+}
 
+__device__ __forceinline__ int wave_incl_add(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(v, o, kWave); if (lane >= o) v += t; }
+  return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(v, o, kWave); if (lane >= o) v = max(v, t); }
+  return v;
+}
+
+// grid (steps in the chunk, n_sub).  LDS: keys[P] (8 B) | hist[16 waves x 256 digits] | wtot[32].
 __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0,
     const int32_t* __restrict__ id_to_type, int64_t N, const int64_t* __restrict__ type_offsets,
     int32_t n_types, const int32_t* __restrict__ type_ids, uint64_t seed, uint64_t global_step0,
-    int32_t padded_size, int32_t mode, int P, int direct, int32_t* __restrict__ prep) {
+    int32_t padded_size, int32_t mode, int direct, int n_pass, int bits, int32_t* __restrict__ prep) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-  int* scan = reinterpret_cast<int*>(keys + P);  // kPrepThreads + 1 ints
-  const int tid = threadIdx.x;
+  const PrepLayout L = prep_layout(B);
+  const int P = (int)L.P, R = P / kPrepThreads;   // R = keys per lane per wave segment (1..16)
+  unsigned* hist = reinterpret_cast<unsigned*>(keys + P);
+  int* wtot = reinterpret_cast<int*>(hist + kPrepWaves * kMaxRadix);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int sub = blockIdx.y;
   const int64_t s = s0 + blockIdx.x;
   const int32_t* pos = triples + 3 * step_row(first_row, T, B, s);
-  int32_t* neg = prep + (int64_t)blockIdx.x * prep_stride(B);
-  int32_t* occ = neg + off_occ(B);
-  int32_t* items = neg + off_items(B);
-  int32_t* n_items = neg + off_nitems(B);
-  int32_t* slot_item = neg + off_slot_item(B);
-  int32_t* islots = neg + off_islots(B);          // per item: its <= 16 slot ids inline (-1 padded)
-  int32_t* item_cnt = neg + off_item_cnt(B);   // followed by row_cnt: 8B counters zeroed here, used once
-  for (int i = tid; i < 6 * B; i += kPrepThreads) slot_item[i] = -1;
-  for (int i = tid; i < 8 * B; i += kPrepThreads) item_cnt[i] = 0;
+  int32_t* rec = prep + (int64_t)blockIdx.x * L.stride;
+  int32_t* neg = rec;
+  int32_t* slot_item = rec + L.off_slot;
+  int32_t* subrec = rec + L.off_sub + sub * L.sub_stride;
+  int32_t* items = subrec + L.off_items;
+  int32_t* islots = subrec + L.off_islots;
+  const int64_t i0 = (int64_t)sub * kSub;
+  const int S = (int)((B - i0) < kSub ? (B - i0) : kSub);     // pairs of this sub-batch
   const uint64_t step = global_step0 + (uint64_t)s;
   const bool batch_heads = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, step) : false;
   constexpr unsigned long long kInvalid = ~0ull;
 
-  for (int i = tid; i < B; i += kPrepThreads) {
-    int32_t p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-    int col;
-    const int32_t repl = corrupt_one(p, i, batch_heads, id_to_type, N, type_offsets, n_types, type_ids,
-                                     seed, step, padded_size, mode, col);
-    int32_t n[3] = {p[0], p[1], p[2]};
-    n[col] = repl;
-    neg[3 * i] = n[0]; neg[3 * i + 1] = n[1]; neg[3 * i + 2] = n[2];
-    const bool bad = p[0] < 0 || p[1] < 0 || p[2] < 0 || p[0] >= N || p[1] >= N || p[2] >= N ||
-                     repl < 0 || repl >= N;
-    // IndexedSlices slots of pair i (ge_hip.h): h+ 0, t+ 1, r+ 2, h- 3, t- 4, r- 5; a negative-side
-    // slot exists only where the row differs from the positive one.
+  if (direct)
+    for (int i = tid; i < 6 * S; i += kPrepThreads) slot_item[6 * i0 + i] = -1;
+
+  // ---- phase 1: negatives + sort keys, in slot order (key index 4*pair + k  <->  ascending slot id)
+  for (int il = tid; il < (int)L.S; il += kPrepThreads) {
+    if (il < S) {
+      const int64_t i = i0 + il;
+      int32_t p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+      int col;
+      const int32_t repl = corrupt_one(p, i, batch_heads, id_to_type, N, type_offsets, n_types, type_ids,
+                                       seed, step, padded_size, mode, col);
+      int32_t n[3] = {p[0], p[1], p[2]};
+      n[col] = repl;
+      neg[3 * i] = n[0]; neg[3 * i + 1] = n[1]; neg[3 * i + 2] = n[2];
+      const bool bad = p[0] < 0 || p[1] < 0 || p[2] < 0 || p[0] >= N || p[1] >= N || p[2] >= N ||
+                       repl < 0 || repl >= N;
+      // IndexedSlices slots of pair i (ge_hip.h): h+ 0, t+ 1, r+ 2, h- 3, t- 4, r- 5; a negative-side
+      // slot exists only where the row differs from the positive one.
 #pragma unroll
-    for (int X = 0; X < 3; ++X)
-      keys[4 * i + X] = bad ? kInvalid : (((unsigned long long)(uint32_t)p[X] << 32) | (uint32_t)(6 * i + X));
-    keys[4 * i + 3] = (bad || repl == p[col]) ? kInvalid
-                                              : (((unsigned long long)(uint32_t)repl << 32) | (uint32_t)(6 * i + 3 + col));
+      for (int X = 0; X < 3; ++X)
+        keys[4 * il + X] = bad ? kInvalid : (((unsigned long long)(uint32_t)p[X] << 32) | (uint32_t)(6 * i + X));
+      keys[4 * il + 3] = (bad || repl == p[col]) ? kInvalid
+                                                 : (((unsigned long long)(uint32_t)repl << 32) | (uint32_t)(6 * i + 3 + col));
+    } else {
+#pragma unroll
+      for (int X = 0; X < 4; ++X) keys[4 * il + X] = kInvalid;
+    }
   }
-  for (int i = 4 * (int)B + tid; i < P; i += kPrepThreads) keys[i] = kInvalid;
   __syncthreads();
 
-  // bitonic sort, ascending by (row, slot)
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (P >> 1); t += kPrepThreads) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const unsigned long long a = keys[i], b = keys[l];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+  // ---- phase 2: stable LSD radix sort by row.  Wave w owns the contiguous segment [w*64R, (w+1)*64R);
+  // in round r its lanes hold elements w*64R + r*64 + lane.  Rank inside (wave, digit) = the wave's
+  // running digit counter + the number of lower lanes with the same digit in this round (ballots).
+  const int radix = 1 << bits;
+  const unsigned dmask = (unsigned)radix - 1u;
+  const int seg = kWave * R;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int shift = 32 + pass * bits;
+    for (int i = tid; i < radix * kPrepWaves; i += kPrepThreads) hist[i] = 0;
+    __syncthreads();
+    unsigned long long k[16];
+    unsigned off[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < R) {
+        k[r] = keys[wave * seg + r * kWave + lane];
+        const unsigned dg = (unsigned)(k[r] >> shift) & dmask;
+        unsigned long long peers = ~0ull;
+        for (int b = 0; b < bits; ++b) {
+          const bool bit = (dg >> b) & 1u;
+          const unsigned long long bal = __ballot(bit);
+          peers &= bit ? bal : ~bal;
+        }
+        const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        const unsigned cnt = (unsigned)__popcll(peers);
+        unsigned* hp = hist + dg * kPrepWaves + wave;
+        const unsigned base = *hp;                       // same value for every peer ...
+        __builtin_amdgcn_wave_barrier();
+        if (rank == 0) *hp = base + cnt;                 // ... then the lowest peer advances the counter
+        __builtin_amdgcn_wave_barrier();
+        off[r] = base + rank;
       }
-      __syncthreads();
     }
+    __syncthreads();
+    {  // exclusive scan of hist in (digit, wave) order
+      const int q = radix * kPrepWaves / kPrepThreads;   // 1, 2 or 4 consecutive counters per thread
+      unsigned loc[4];
+      int sum = 0;
+      for (int u = 0; u < q; ++u) { loc[u] = hist[tid * q + u]; sum += (int)loc[u]; }
+      const int incl = wave_incl_add(sum, lane);
+      if (lane == kWave - 1) wtot[wave] = incl;
+      __syncthreads();
+      int run = incl - sum;
+      for (int w = 0; w < wave; ++w) run += wtot[w];
+      for (int u = 0; u < q; ++u) { hist[tid * q + u] = (unsigned)run; run += (int)loc[u]; }
+    }
+    __syncthreads();   // every key is in registers: the scatter may overwrite the one LDS buffer
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < R) {
+        const unsigned dg = (unsigned)(k[r] >> shift) & dmask;
+        keys[hist[dg * kPrepWaves + wave] + off[r]] = k[r];
+      }
+    }
+    __syncthreads();
   }
 
-  // work items: cut every run of equal rows into pieces of <= kItemCap entries, counted from the
-  // start of the run (so a row with <= kItemCap occurrences is always exactly one item).
-  const int per = P / kPrepThreads;  // P >= kPrepThreads
-  const int base = tid * per;
-  auto rowof = [&](int i) -> uint32_t { return (uint32_t)(keys[i] >> 32); };
-  auto valid = [&](int i) -> bool { return keys[i] != kInvalid; };
-  auto is_head = [&](int i) -> bool { return valid(i) && (i == 0 || rowof(i) != rowof(i - 1)); };
-  // a row with exactly one gradient slot in the step has one reader and one writer -- the same pair:
-  // with `direct` it is not queued as an item, its slot is tagged kSlotDirect and the producing pair
-  // updates the table row itself (no gradient-row round trip, no counter)
-  auto is_sole = [&](int i) -> bool {
-    return direct && is_head(i) && !(i + 1 < P && valid(i + 1) && rowof(i + 1) == rowof(i));
-  };
-  // (a) run start of every position: block-wide max-scan of the last head position per thread chunk
-  int last_head = -1;
-  for (int i = base; i < base + per; ++i) if (is_head(i)) last_head = i;
-  scan[tid] = last_head;
-  __syncthreads();
-  for (int off = 1; off < kPrepThreads; off <<= 1) {
-    const int v = (tid >= off) ? scan[tid - off] : -1;
-    __syncthreads();
-    scan[tid] = max(scan[tid], v);
-    __syncthreads();
-  }
-  const int carry = (tid == 0) ? -1 : scan[tid - 1];
-  __syncthreads();
-  // (b) count item starts in this chunk, exclusive-scan the counts
-  int cnt = 0;
+  // ---- phase 3: work items.  Every run of equal rows is cut into pieces of <= kItemCap entries counted
+  // from the start of the run (a row with <= kItemCap occurrences is always exactly one item).  With
+  // `direct`, a row with exactly ONE gradient slot in the step has one reader and one writer -- the same
+  // pair: it is not queued, its slot is tagged kSlotDirect and the producing pair updates the table row.
+  auto key_at = [&](int i) -> unsigned long long { return (i >= 0 && i < P) ? keys[i] : kInvalid; };
+  int rs_loc[16];          // (a) run start of every position: max-scan of head positions
   {
-    int rs = carry;
-    for (int i = base; i < base + per; ++i) {
-      if (is_head(i)) rs = i;
-      if (valid(i) && ((i - rs) % kItemCap) == 0 && !is_sole(i)) ++cnt;
+    int carry = -1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < R) {
+        const int i = wave * seg + r * kWave + lane;
+        const unsigned long long kk = keys[i], kp = key_at(i - 1);
+        const bool head = kk != kInvalid && (i == 0 || (uint32_t)(kp >> 32) != (uint32_t)(kk >> 32));
+        const int m = max(wave_incl_max(head ? i : -1, lane), carry);
+        rs_loc[r] = m;
+        carry = __shfl(m, kWave - 1, kWave);
+      }
     }
+    if (lane == 0) wtot[wave] = carry;
   }
-  scan[tid] = cnt;
   __syncthreads();
-  for (int off = 1; off < kPrepThreads; off <<= 1) {  // inclusive Hillis-Steele scan
-    const int v = (tid >= off) ? scan[tid - off] : 0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  int prev_max = -1;
+  for (int w = 0; w < wave; ++w) prev_max = max(prev_max, wtot[w]);
+  __syncthreads();
+  unsigned start_mask = 0;   // (b) item starts, counted
+  int idx_loc[16];
+  {
+    int carry = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < R) {
+        const int i = wave * seg + r * kWave + lane;
+        const unsigned long long kk = keys[i], kp = key_at(i - 1), kn = key_at(i + 1);
+        const bool valid = kk != kInvalid;
+        const uint32_t row = (uint32_t)(kk >> 32);
+        const bool head = valid && (i == 0 || (uint32_t)(kp >> 32) != row);
+        const bool sole = direct && head && !(kn != kInvalid && (uint32_t)(kn >> 32) == row);
+        const int rs = max(rs_loc[r], prev_max);
+        rs_loc[r] = rs;
+        const bool start = valid && ((i - rs) % kItemCap) == 0 && !sole;
+        if (start) start_mask |= 1u << r;
+        if (sole) slot_item[(uint32_t)kk] = kSlotDirect;
+        const int incl = wave_incl_add(start ? 1 : 0, lane) + carry;
+        idx_loc[r] = incl - (start ? 1 : 0);
+        carry = __shfl(incl, kWave - 1, kWave);
+      }
+    }
+    if (lane == 0) wtot[wave] = carry;
   }
-  int idx = scan[tid] - cnt;  // exclusive prefix
-  if (tid == kPrepThreads - 1) n_items[0] = scan[tid];
-  // (c) emit items and the slot list
-  int rs = carry;
-  for (int i = base; i < base + per; ++i) {
-    if (i < 4 * B) occ[i] = valid(i) ? (int32_t)(uint32_t)keys[i] : -1;
-    if (!valid(i)) continue;
-    if (is_head(i)) rs = i;
-    if (((i - rs) % kItemCap) != 0) continue;
-    if (is_sole(i)) { slot_item[(uint32_t)keys[i]] = kSlotDirect; continue; }
-    const uint32_t r = rowof(i);
-    int e = i + 1;
-    while (e < P && (e - i) < kItemCap && valid(e) && rowof(e) == r) ++e;
-    const bool more = (e < P && valid(e) && rowof(e) == r);
-    const bool multi = (i != rs) || more;
-    const int ordinal = (i - rs) / kItemCap;     // items of one row are consecutive
-    items[5 * idx] = (int32_t)r;
-    items[5 * idx + 1] = i;
-    items[5 * idx + 2] = (e - i) | (multi ? (1 << 30) : 0);
-    items[5 * idx + 3] = idx - ordinal;          // the row's first item
-    if (!more) items[5 * (idx - ordinal) + 4] = ordinal + 1;  // the row's item count, kept at its first item
-    for (int j = i; j < e; ++j) slot_item[(uint32_t)keys[j]] = idx;
-    for (int j = 0; j < kItemCap; ++j) islots[idx * kItemCap + j] = (i + j < e) ? (int32_t)(uint32_t)keys[i + j] : -1;
-    ++idx;
+  __syncthreads();
+  int prev_items = 0, total = 0;
+  for (int w = 0; w < kPrepWaves; ++w) { if (w < wave) prev_items += wtot[w]; total += wtot[w]; }
+  if (tid == 0) subrec[0] = total;
+  // (c) emit
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < R && ((start_mask >> r) & 1u)) {
+      const int i = wave * seg + r * kWave + lane;
+      const uint32_t row = (uint32_t)(keys[i] >> 32);
+      const int idx = prev_items + idx_loc[r];
+      int e = i + 1;
+      while (e < P && (e - i) < kItemCap && keys[e] != kInvalid && (uint32_t)(keys[e] >> 32) == row) ++e;
+      const bool more = (e < P && keys[e] != kInvalid && (uint32_t)(keys[e] >> 32) == row);
+      const bool multi = (i != rs_loc[r]) || more;
+      items[2 * idx] = (int32_t)row;
+      items[2 * idx + 1] = (e - i) | (multi ? (1 << 30) : 0);
+#pragma unroll
+      for (int j = 0; j < kItemCap; ++j)
+        islots[idx * kItemCap + j] = (i + j < e) ? (int32_t)(uint32_t)keys[i + j] : -1;
+    }
   }
 }
 
 // One wavefront per work item: sum the item's gradient rows (skipping slots whose pair was
 // hinge-inactive: grad_idx < 0), then table[row] += sum -- plain RMW when the row has a single
-// item, atomics when it was split.  Lane l owns columns l, l+64, ... (256 contiguous bytes per
-// wave instruction for loads, stores and atomics alike).
+// item, atomics when it was split (or when the step has several sub-batches, blockIdx.y, whose items
+// may share rows).  Lane l owns columns l, l+64, ... (256 contiguous bytes per wave instruction for
+// loads, stores and atomics alike).
 template <int NJ>
 __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
-    float* __restrict__ table, int d, const int32_t* __restrict__ items,
-    const int32_t* __restrict__ n_items_ptr, const int32_t* __restrict__ islots,
-    const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val) {
+    float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
+    int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
-  const int n_items = n_items_ptr[0];
+  const int32_t* subrec = sub0 + (int64_t)blockIdx.y * sub_stride;
+  const int32_t* items = subrec + off_items;
+  const int32_t* islots = subrec + off_islots;
+  const bool shared_rows = gridDim.y > 1;
+  const int n_items = subrec[0];
   for (int w = wave; w < n_items; w += nwaves) {
     // two independent loads first: the item header and its inline slot list (lane o < 16 -> slot o)
-    const int row = items[5 * w], cm = items[5 * w + 2];
+    const int row = items[2 * w], cm = items[2 * w + 1];
     int slot_v = (lane < kItemCap) ? islots[w * kItemCap + lane] : -1;
     const int cnt = cm & 0x3FFFFFFF;
-    const bool multi = (cm >> 30) & 1;
+    const bool multi = ((cm >> 30) & 1) || shared_rows;
     float* dst = table + (int64_t)row * d;
     // the table row is fetched now, under the gradient-row loads, not after them
     float base[NJ];
@@ -275,12 +347,13 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
   }
 }
 
-static int apply_sorted_launch(float* table, int d, int64_t B, const int32_t* items, const int32_t* n_items,
-                               const int32_t* islots, const int32_t* gidx, const float* gval, hipStream_t st,
-                               hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const int grid = grid_for(4 * B, kBlock / kWave);  // at most 4B items
+static int apply_sorted_launch(float* table, int d, const PrepLayout& L, const int32_t* step_rec,
+                               const int32_t* gidx, const float* gval, hipStream_t st, hipEvent_t ev_start,
+                               hipEvent_t ev_stop) {
+  const int grid = grid_for(L.P, kBlock / kWave);  // at most P items per sub-batch
   const int nj = (d + kWave - 1) / kWave;
-#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, items, n_items, islots, gidx, gval)
+  const dim3 g((unsigned)grid, (unsigned)L.n_sub);
+#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + L.off_sub, L.sub_stride, (int)L.off_items, (int)L.off_islots, gidx, gval)
   if (nj <= 1) LA(1); else if (nj <= 2) LA(2); else if (nj <= 4) LA(4); else if (nj <= 8) LA(8); else if (nj <= 16) LA(16);
   else return GE_ENOTSUP;
 #undef LA
@@ -293,22 +366,27 @@ size_t hinge_ws_bytes(int64_t B, int32_t d) {
   return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + align_up_sz(sizeof(float) * 6 * (size_t)B * (size_t)d, 256);
 }
 
-bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= kFastMaxB && d <= 1024; }
+bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= (int64_t)1 << 24 && d <= 1024; }
 
-// training workspace: [gidx 6B][gval RING x (6B x gs)][partials 4B x gs][prep buffer 0][prep buffer 1],
-// gs = gradient-row stride padded to whole 128-byte lines (the fused kernel's publish unit).
+// steps prepared per launch: 32 at B <= 4096 (one record is ~1.2 MB there), fewer for large batches so
+// that a chunk stays near 40 MB
+static int64_t prep_chunk_steps(int64_t B) {
+  int64_t c = (32 * kSub) / (B < kSub ? kSub : B);
+  return c < 2 ? 2 : c;
+}
+
+// training workspace: [gidx 6B][gval RING x (6B x d)][prep chunk buffer 0][prep chunk buffer 1].
 // The gradient rows go to a RING of regions, one per step in turn: a region is written by the grad kernel
 // on one XCD and read by the apply kernel on another, and rewriting lines that still sit in another XCD's
 // L2 costs ~3.7 us per 13 MB (tools/xcd_locality_probe.hip: 9.1 vs 5.4 us); by the time a region comes
 // round again (normally 4 steps later, > the 32 MB of L2 in between) its lines have been evicted and the
 // stores take the fast path.
 static size_t grad_region_bytes(int64_t B, int32_t d) {
-  return align_up_sz(sizeof(float) * 6 * (size_t)B * (size_t)fused_gstride(d), 256);
+  return align_up_sz(sizeof(float) * 6 * (size_t)B * (size_t)d, 256);
 }
 static int grad_ring(int64_t B, int32_t d) {
   const size_t reg = grad_region_bytes(B, d);
-  if (const char* e = getenv("GE_GRAD_RING")) { const int v = atoi(e); if (v >= 1 && v <= 64) return v; }   // tuning
-  // measured at B=4096, d=200 (22 MB regions): 1 -> 22.4, 2 -> 21.3, 4 -> 21.0, 8 -> 21.0, 16 -> 21.8, 32 -> 22.8 us/step:
+  // measured at B=4096, d=200 (20 MB regions): 1 -> 22.4, 2 -> 21.3, 4 -> 21.0, 8 -> 21.0, 16 -> 21.8, 32 -> 22.8 us/step:
   // long enough to outlive the L2s, short enough to stay inside the 256 MB Infinity Cache
   size_t r = ((size_t)64 << 20) / reg + 1;
   if (r < 2) r = 2;
@@ -317,59 +395,93 @@ static int grad_ring(int64_t B, int32_t d) {
   return (int)r;
 }
 static size_t train_grad_bytes(int64_t B, int32_t d) {
-  const size_t gs = (size_t)fused_gstride(d);
-  return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + (size_t)grad_ring(B, d) * grad_region_bytes(B, d) +
-         align_up_sz(sizeof(float) * 4 * (size_t)B * gs, 256);
+  return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + (size_t)grad_ring(B, d) * grad_region_bytes(B, d);
+}
+static size_t prep_chunk_bytes(int64_t B) {
+  return align_up_sz(sizeof(int32_t) * (size_t)prep_chunk_steps(B) * (size_t)prep_layout(B).stride, 256);
 }
 size_t train_ws_bytes(int64_t B, int32_t d) {
   if (!train_fast_ok(B, d)) return hinge_ws_bytes(B, d);
-  return train_grad_bytes(B, d) + 2 * sizeof(int32_t) * (size_t)kPrepChunk * (size_t)prep_stride(B);  // double-buffered
+  return train_grad_bytes(B, d) + 2 * prep_chunk_bytes(B);  // double-buffered
 }
 
-static int prep_pow2(int64_t B) {
-  int P = kPrepThreads;
-  while (P < 4 * B) P <<= 1;
-  return P;
+static size_t prep_lds_bytes(const PrepLayout& L) {
+  return sizeof(unsigned long long) * (size_t)L.P + sizeof(unsigned) * kPrepWaves * kMaxRadix + sizeof(int) * 32;
 }
 
-// The prepare launches never touch the table, so they run on a side stream, one chunk ahead of the
-// steps that consume them (double-buffered), and disappear behind the training kernels.  The side
-// stream and its 4 events are the only state the library keeps; they are created on first use, one
-// set per device.
-struct AuxState {
-  hipStream_t stream = nullptr;
-  hipEvent_t prep_done[2] = {nullptr, nullptr};
-  hipEvent_t buf_free[2] = {nullptr, nullptr};
-  hipEvent_t entry = nullptr;
-  bool attr_set = false;
-};
-static AuxState g_aux[16];
-
-static int aux_for_current_device(AuxState** out) {
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
+static int prepare_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n,
+                          const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
+                          const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
+                          int32_t mode, int direct, int32_t* out, hipStream_t st) {
+  const PrepLayout L = prep_layout(B);
+  int nbits = 1;
+  while (((int64_t)1 << nbits) <= N) ++nbits;          // the value N itself (and above) is free for invalid keys
+  const int n_pass = (nbits + 7) / 8;
+  int bits = (nbits + n_pass - 1) / n_pass;
+  if (bits < 6) bits = 6;                              // >= 1024 counters: one per thread in the scan
+  const size_t lds = prep_lds_bytes(L);
+  // per device, idempotent and cheap: no cached flag, so no state and nothing to get stale on a second device
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_prepare_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return (int)e;
-  if (dev < 0 || dev >= 16) return GE_ENOTSUP;
-  AuxState& a = g_aux[dev];
-  if (!a.stream) {
-    if ((e = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking)) != hipSuccess) return (int)e;
-    for (int i = 0; i < 2; ++i) {
-      if ((e = hipEventCreateWithFlags(&a.prep_done[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
-      if ((e = hipEventCreateWithFlags(&a.buf_free[i], hipEventDisableTiming)) != hipSuccess) return (int)e;
-    }
-    if ((e = hipEventCreateWithFlags(&a.entry, hipEventDisableTiming)) != hipSuccess) return (int)e;
-  }
-  if (!a.attr_set) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_prepare_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    a.attr_set = true;
-  }
-  *out = &a;
-  return 0;
+  hipLaunchKernelGGL(train_prepare_kernel, dim3((unsigned)n, (unsigned)L.n_sub), dim3(kPrepThreads), lds, st, triples,
+                     T, first_row, B, s0, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
+                     padded_size, mode, direct, n_pass, bits, out);
+  return launch_status();
 }
 
 #define GE_HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// ------------------------------------------------------------------ the pipeline handle (host object)
+// Identity of the sequence of prepared steps + which chunk each of the two workspace buffers holds.
+struct Pipeline {
+  int device = -1;
+  hipStream_t side = nullptr;
+  hipEvent_t prep_done[2] = {nullptr, nullptr};
+  hipEvent_t buf_free[2] = {nullptr, nullptr};
+  bool live = false;
+  const int32_t* triples = nullptr; const int32_t* id_to_type = nullptr; const int64_t* type_offsets = nullptr;
+  const int32_t* type_ids = nullptr; void* workspace = nullptr;
+  int64_t T = 0, B = 0, N = 0, origin_row = 0, next_abs = 0, resident[2] = {-1, -1};
+  uint64_t seed = 0, origin_gs = 0;
+  int32_t n_types = 0, padded_size = 0, mode = 0, d = 0;
+  int direct = 0;
+};
+
+int pipeline_create(void** out) {
+  Pipeline* p = new Pipeline();
+  hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipEventCreateWithFlags(&p->prep_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->buf_free[i], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) { delete p; return (int)e; }
+  *out = p;
+  return 0;
+}
+int pipeline_reset(void* h) {
+  if (!h) return GE_EINVAL;
+  static_cast<Pipeline*>(h)->live = false;
+  return 0;
+}
+int pipeline_destroy(void* h) {
+  if (!h) return GE_EINVAL;
+  Pipeline* p = static_cast<Pipeline*>(h);
+  if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
+  for (int i = 0; i < 2; ++i) {
+    if (p->prep_done[i]) (void)hipEventDestroy(p->prep_done[i]);
+    if (p->buf_free[i]) (void)hipEventDestroy(p->buf_free[i]);
+  }
+  delete p;
+  return 0;
+}
+
+static inline int64_t norm_row(int64_t first_row, int64_t T, int64_t B) {
+  int64_t f = first_row % T;
+  if (f + B > T) f = 0;
+  return f;
+}
 
 int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,
                     int64_t B, int64_t n_steps, const int32_t* id_to_type, const int64_t* type_offsets,
@@ -377,48 +489,70 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
                     int32_t padded_size, int32_t mode, float margin, float lr0, float decay_steps,
                     float decay_rate, float max_norm, int model, float* loss, int keep_all_losses,
                     int32_t* neg_ws, void* workspace, size_t workspace_bytes, void** ev_pairs, int ev_kernel,
-                    hipStream_t st) {
+                    void* pipe_handle, hipStream_t st) {
+  if (n_steps <= 0) return 0;
   int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
   float* gval0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256));
   const bool fast = train_fast_ok(B, d) && workspace_bytes >= train_ws_bytes(B, d);
-  const size_t grow = (size_t)fused_gstride(d);  // floats per gradient row in the fused layout
   const int ring = fast ? grad_ring(B, d) : 1;
   const size_t region_floats = grad_region_bytes(B, d) / sizeof(float);
-  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(gval0) + (size_t)ring * grad_region_bytes(B, d));
+  const PrepLayout L = prep_layout(B);
+  const int64_t K = prep_chunk_steps(B);
   int32_t* prep_base = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + train_grad_bytes(B, d));
-  int lpt_, niter_;
-  const bool fused = fast && model == 0 && fused_enabled() && fused_shape_ok(d, table, lpt_, niter_);
-  const int64_t buf_ints = (int64_t)kPrepChunk * prep_stride(B);
-  const int P = prep_pow2(B);
-  const size_t lds = sizeof(unsigned long long) * (size_t)P + sizeof(int) * (kPrepThreads + 1);
-  AuxState* aux = nullptr;
-  if (fast && n_steps > 0) {
-    int rc = aux_for_current_device(&aux);
-    if (rc) return rc;
-    // earlier work on `st` may still be reading the prep buffers / writing the triples
-    GE_HIP_TRY(hipEventRecord(aux->entry, st));
-    GE_HIP_TRY(hipStreamWaitEvent(aux->stream, aux->entry, 0));
+  const int64_t buf_ints = (int64_t)(prep_chunk_bytes(B) / sizeof(int32_t));
+  const int direct = (L.n_sub == 1 && model == 0) ? 1 : 0;   // sole-slot rows updated by the producing pair
+  Pipeline* pipe = fast ? static_cast<Pipeline*>(pipe_handle) : nullptr;
+  Pipeline local;               // no handle: prepare on the caller's stream, nothing survives the call
+  int64_t base_abs = 0;
+  if (fast) {
+    if (pipe) {
+      int dev = -1;
+      GE_HIP_TRY(hipGetDevice(&dev));
+      if (dev != pipe->device) return GE_EINVAL;
+      const bool cont = pipe->live && pipe->triples == triples && pipe->id_to_type == id_to_type &&
+                        pipe->type_offsets == type_offsets && pipe->type_ids == type_ids &&
+                        pipe->workspace == workspace && pipe->T == T && pipe->B == B && pipe->N == N &&
+                        pipe->seed == seed && pipe->n_types == n_types && pipe->padded_size == padded_size &&
+                        pipe->mode == mode && pipe->d == d && pipe->direct == direct &&
+                        global_step0 == pipe->origin_gs + (uint64_t)pipe->next_abs &&
+                        norm_row(first_row, T, B) == step_row(pipe->origin_row, T, B, pipe->next_abs);
+      if (!cont) {
+        pipe->live = true;
+        pipe->triples = triples; pipe->id_to_type = id_to_type; pipe->type_offsets = type_offsets;
+        pipe->type_ids = type_ids; pipe->workspace = workspace; pipe->T = T; pipe->B = B; pipe->N = N;
+        pipe->seed = seed; pipe->n_types = n_types; pipe->padded_size = padded_size; pipe->mode = mode;
+        pipe->d = d; pipe->direct = direct;
+        pipe->origin_row = norm_row(first_row, T, B); pipe->origin_gs = global_step0; pipe->next_abs = 0;
+        pipe->resident[0] = pipe->resident[1] = -1;
+      }
+      base_abs = pipe->next_abs;
+    } else {
+      pipe = &local;
+      pipe->origin_row = norm_row(first_row, T, B); pipe->origin_gs = global_step0;
+      pipe->side = st;
+    }
   }
-  auto launch_prepare = [&](int64_t chunk) -> int {
-    const int64_t s0 = chunk * kPrepChunk;
-    const int64_t todo = (n_steps - s0) < kPrepChunk ? (n_steps - s0) : kPrepChunk;
-    int32_t* buf = prep_base + (chunk & 1) * buf_ints;
-    hipLaunchKernelGGL(train_prepare_kernel, dim3((unsigned)todo), dim3(kPrepThreads), lds, aux->stream, triples, T,
-                       first_row, B, s0, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
-                       padded_size, mode, P, model == 0 ? 1 : 0, buf);
-    int rc = launch_status();
+  const bool own_side = fast && pipe != &local;
+  // chunk c of the sequence -> buffer c & 1.  Before a prepare launch overwrites a buffer, the side
+  // stream waits for everything enqueued on `st` so far: that includes every step of the chunk that
+  // held the buffer before, and (first launch) earlier work that may still be writing `triples`.
+  auto ensure_chunk = [&](int64_t c) -> int {
+    const int b = (int)(c & 1);
+    if (pipe->resident[b] == c) return 0;
+    if (own_side) {
+      GE_HIP_TRY(hipEventRecord(pipe->buf_free[b], st));
+      GE_HIP_TRY(hipStreamWaitEvent(pipe->side, pipe->buf_free[b], 0));
+    }
+    int rc = prepare_launch(triples, T, pipe->origin_row, B, c * K, K, id_to_type, N, type_offsets, n_types, type_ids,
+                            seed, pipe->origin_gs, padded_size, mode, direct, prep_base + b * buf_ints, pipe->side);
     if (rc) return rc;
-    GE_HIP_TRY(hipEventRecord(aux->prep_done[chunk & 1], aux->stream));
+    if (own_side) GE_HIP_TRY(hipEventRecord(pipe->prep_done[b], pipe->side));
+    pipe->resident[b] = c;
     return 0;
   };
-  if (fast && n_steps > 0) {
-    int rc = launch_prepare(0);
-    if (rc) return rc;
-  }
   auto lr_at = [&](uint64_t gs) {
     return decay_steps > 0.f ? lr0 / (1.0f + decay_rate * ((float)gs / decay_steps)) : lr0;
   };
-  const int64_t n_chunks = (n_steps + kPrepChunk - 1) / kPrepChunk;
   for (int64_t s = 0; s < n_steps; ++s) {
     const uint64_t gs = global_step0 + (uint64_t)s;
     const float lr = lr_at(gs);
@@ -428,22 +562,23 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     hipEvent_t e1 = ev_pairs ? (hipEvent_t)ev_pairs[2 * s + 1] : nullptr;
     int rc;
     const int32_t* neg;
-    const int32_t* step_prep = nullptr;
+    const int32_t* step_rec = nullptr;
     if (e0 && ev_kernel == 0) (void)hipEventRecord(e0, st);
     if (fast) {
-      const int64_t chunk = s / kPrepChunk, in_chunk = s % kPrepChunk;
-      if (in_chunk == 0) {
-        // the next chunk is prepared on the side stream while this one trains; its buffer was last
-        // read by chunk-1, whose completion `buf_free` marks
-        if (chunk + 1 < n_chunks) {
-          if (chunk >= 1) GE_HIP_TRY(hipStreamWaitEvent(aux->stream, aux->buf_free[(chunk + 1) & 1], 0));
-          rc = launch_prepare(chunk + 1);
+      const int64_t abs_s = base_abs + s, chunk = abs_s / K, in_chunk = abs_s % K;
+      if (s == 0 || in_chunk == 0) {
+        rc = ensure_chunk(chunk);
+        if (rc) return rc;
+        // the next chunk is prepared on the side stream while this one trains -- also when it lies beyond
+        // this call's last step: the call that continues from there finds it done
+        if (own_side) {
+          rc = ensure_chunk(chunk + 1);
           if (rc) return rc;
+          GE_HIP_TRY(hipStreamWaitEvent(st, pipe->prep_done[chunk & 1], 0));
         }
-        GE_HIP_TRY(hipStreamWaitEvent(st, aux->prep_done[chunk & 1], 0));
       }
-      step_prep = prep_base + (chunk & 1) * buf_ints + in_chunk * prep_stride(B);
-      neg = step_prep;
+      step_rec = prep_base + (chunk & 1) * buf_ints + in_chunk * L.stride;
+      neg = step_rec;
     } else {
       rc = corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, gs, padded_size,
                                 mode, neg_ws, st);
@@ -456,35 +591,48 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     // they report the kernel's own begin/end timestamps, like rocprofv3's kernel trace
     hipEvent_t g0 = ev_kernel == 1 ? e0 : nullptr, g1 = ev_kernel == 1 ? e1 : nullptr;
     hipEvent_t a0 = ev_kernel == 2 ? e0 : nullptr, a1 = ev_kernel == 2 ? e1 : nullptr;
-    if (fused) {
-      // one launch per step: gradients + sparse update ("last arriver executes", ge_fused.hip)
-      int32_t* sp = const_cast<int32_t*>(step_prep);
-      FusedArgs fa{sp + off_slot_item(B), sp + off_items(B), sp + off_occ(B), sp + off_item_cnt(B),
-                   sp + off_row_cnt(B), partials, gidx, gval, (int)grow, 0};
-      rc = complex_fused_step_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, fa, st, g0, g1);
-      if (rc) return rc;
-      if (a0) { (void)hipEventRecord(a0, st); (void)hipEventRecord(a1, st); }
-      if ((s % kPrepChunk) == kPrepChunk - 1 || s == n_steps - 1)
-        GE_HIP_TRY(hipEventRecord(aux->buf_free[(s / kPrepChunk) & 1], st));
-      continue;
-    }
-    rc = model == 0 ? complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1,
-                                                fast ? step_prep + off_slot_item(B) : nullptr)
-                    : hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1);
+    const bool dir = fast && direct;
+    rc = model == 1 ? hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1)
+                    : complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1,
+                                                dir ? step_rec + L.off_slot : nullptr, dir ? table : nullptr);
     if (rc) return rc;
-    if (fast) rc = apply_sorted_launch(table, d, B, step_prep + off_items(B), step_prep + off_nitems(B), step_prep + off_islots(B), gidx, gval, st, a0, a1);
+    if (fast) rc = apply_sorted_launch(table, d, L, step_rec, gidx, gval, st, a0, a1);
     else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
     if (rc) return rc;
-    if (fast && ((s % kPrepChunk) == kPrepChunk - 1 || s == n_steps - 1))
-      GE_HIP_TRY(hipEventRecord(aux->buf_free[(s / kPrepChunk) & 1], st));
   }
-  // keep the caller's neg_ws meaningful: the last step's negatives
-  if (fast && n_steps > 0) {
-    const int64_t ls = n_steps - 1;
-    const int32_t* last = prep_base + ((ls / kPrepChunk) & 1) * buf_ints + (ls % kPrepChunk) * prep_stride(B);
+  if (fast) {
+    // keep the caller's neg_ws meaningful: the last step's negatives
+    const int64_t la = base_abs + n_steps - 1;
+    const int32_t* last = prep_base + ((la / K) & 1) * buf_ints + (la % K) * L.stride;
     GE_HIP_TRY(hipMemcpyAsync(neg_ws, last, sizeof(int32_t) * 3 * (size_t)B, hipMemcpyDeviceToDevice, st));
+    if (own_side) {
+      // the look-ahead launch writes into the caller's workspace after this call returns: order it before
+      // whatever the caller enqueues on `st` next (e.g. a stream-ordered free of the workspace)
+      GE_HIP_TRY(hipStreamWaitEvent(st, pipe->prep_done[((la / K) + 1) & 1], 0));
+      pipe->next_abs = base_abs + n_steps;
+    }
   }
   return 0;
+}
+
+// prepared records of `n_steps` consecutive steps into a caller buffer (tests, tools; the sharded
+// path's planner): the same launch ge_train_steps uses.
+int train_prepare_run(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t n_steps,
+                      const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
+                      const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
+                      int32_t mode, int direct, int32_t* out, hipStream_t st) {
+  if (n_steps == 0) return 0;
+  const PrepLayout L = prep_layout(B);
+  if (!direct || L.n_sub == 1)
+    return prepare_launch(triples, T, norm_row(first_row, T, B), B, 0, n_steps, id_to_type, N, type_offsets, n_types,
+                          type_ids, seed, global_step0, padded_size, mode, direct ? 1 : 0, out, st);
+  return GE_EINVAL;   // direct tagging needs the whole step in one sub-batch
+}
+
+void train_prepared_layout(int64_t B, int64_t* out) {
+  const PrepLayout L = prep_layout(B);
+  out[0] = L.stride; out[1] = L.n_sub; out[2] = L.S; out[3] = L.off_slot; out[4] = L.off_sub;
+  out[5] = L.sub_stride; out[6] = L.off_items; out[7] = L.off_islots;
 }
 
 }  // namespace ge

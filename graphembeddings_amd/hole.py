@@ -319,7 +319,8 @@ class Trainer:
     def __init__(self, embeddings: torch.Tensor, triples: torch.Tensor, type_tables: TypeTables,
                  batch_size: int, *, margin: float = 0.2, learning_rate: float = 0.1,
                  decay_steps: float = 0.0, decay_rate: float = 0.5, model="complex", max_norm: float = 1.0,
-                 seed: int = 0, corrupt_mode: int = CORRUPT_BATCH_COIN):
+                 seed: int = 0, corrupt_mode: int = CORRUPT_BATCH_COIN, prepared: bool = True,
+                 lookahead: bool = True):
         self.embeddings = _table(embeddings)
         self.triples = _triples(triples, "triples")
         if self.triples.shape[0] < batch_size:
@@ -332,10 +333,40 @@ class Trainer:
         self.global_step = 0
         self.row = 0
         dev = self.embeddings.device
-        need = _lib.load().ge_train_workspace_bytes(self.B, self.embeddings.shape[1])
+        # prepared=False: only the single-step workspace -> ge_train_steps takes its fallback branch
+        # (per-step sampler launch + float-atomic scatter); lookahead=False: no pipeline handle, the
+        # prepare launches go to the caller's stream and nothing survives between run() calls
+        lib = _lib.load()
+        d = self.embeddings.shape[1]
+        need = lib.ge_train_workspace_bytes(self.B, d) if prepared else lib.ge_hinge_step_workspace_bytes(self.B, d)
         self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
         self._neg = torch.empty(self.B, 3, dtype=torch.int32, device=dev)
         self.last_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        # the prepared-steps pipeline (side stream + look-ahead records that survive between run() calls)
+        self._pipe = None
+        if prepared and lookahead:
+            import ctypes as C
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.call("ge_train_pipeline_create", C.byref(h))
+            self._pipe = h.value
+
+    def close(self):
+        """Release the pipeline handle (waits for its side stream)."""
+        if getattr(self, "_pipe", None):
+            _lib.load().ge_train_pipeline_destroy(self._pipe)
+            self._pipe = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def invalidate(self):
+        """Forget the records prepared ahead (call after changing `triples` or the type tables in place)."""
+        if self._pipe:
+            _lib.call("ge_train_pipeline_reset", self._pipe)
 
     def learning_rate(self, step=None) -> float:
         s = self.global_step if step is None else step
@@ -346,6 +377,7 @@ class Trainer:
         perm = torch.randperm(self.triples.shape[0], device=self.triples.device, generator=generator)
         self.triples = self.triples[perm].contiguous()
         self.row = 0
+        self.invalidate()     # the allocator may hand the new order the address of an older one
 
     def run(self, n_steps: int, *, keep_losses: bool = False, events=None, ev_kernel: int = 2):
         """Enqueue n_steps training steps on the current stream; returns the loss tensor
@@ -363,7 +395,7 @@ class Trainer:
                   self.tt.n_types, self.tt.type_ids.data_ptr(), self.seed & (2**64 - 1), self.global_step,
                   self.tt.padded_size, self.mode, self.margin, self.lr0, self.decay_steps, self.decay_rate,
                   self.max_norm, self.model, loss.data_ptr(), int(keep_losses), self._neg.data_ptr(),
-                  self._ws.data_ptr(), self._ws.numel(), evp, int(ev_kernel), _stream())
+                  self._ws.data_ptr(), self._ws.numel(), evp, int(ev_kernel), self._pipe, _stream())
         # mirror the C loop's row bookkeeping
         row = self.row % T
         for _ in range(n_steps):
@@ -373,6 +405,31 @@ class Trainer:
         self.row = row
         self.global_step += n_steps
         return loss.view(n_steps, self.B) if keep_losses else loss
+
+
+def prepared_layout(batch_size: int):
+    """Word offsets of a prepared step record (ge_train_prepared_layout): (words per step, sub-batches,
+    pairs per sub-batch, slot_item offset, first sub-batch offset, words per sub-batch, items offset,
+    islots offset)."""
+    import ctypes as C
+    out = (C.c_int64 * 8)()
+    _lib.call("ge_train_prepared_layout", int(batch_size), out)
+    return tuple(int(v) for v in out)
+
+
+def prepare_steps(triples: torch.Tensor, type_tables: TypeTables, batch_size: int, n_steps: int, *, first_row: int = 0,
+                  seed: int = 0, global_step: int = 0, mode: int = CORRUPT_BATCH_COIN, direct: bool = False) -> torch.Tensor:
+    """The prepare launch of ge_train_steps on its own (ge_train_prepare_steps): negatives plus the
+    row-sorted work items of `n_steps` consecutive steps as an int32 [n_steps, words] tensor."""
+    tb = _triples(triples, "triples")
+    lay = prepared_layout(batch_size)
+    out = torch.empty(n_steps, lay[0], dtype=torch.int32, device=tb.device)
+    tt = type_tables
+    _lib.call("ge_train_prepare_steps", tb.data_ptr(), tb.shape[0], int(first_row), int(batch_size), int(n_steps),
+              tt.id_to_type.data_ptr(), tt.id_to_type.numel(), tt.type_offsets.data_ptr(), tt.n_types,
+              tt.type_ids.data_ptr(), int(seed) & (2**64 - 1), int(global_step), tt.padded_size, int(mode),
+              int(bool(direct)), out.data_ptr(), out.numel() * 4, _stream())
+    return out
 
 
 class Events:

@@ -9,7 +9,8 @@
  * transE.py:95-112): C linkage, caller-owned caller-sized flat buffers, int32 ids.  Differences
  * that make it usable from a GPU training loop: every entry point returns an int status
  * (0 = ok, <0 = -errno style argument error, >0 = hipError_t), takes the hipStream_t it must
- * enqueue on (as void*), never synchronises, never allocates, and keeps no global state.
+ * enqueue on (as void*), never synchronises, never allocates device memory, and keeps no global
+ * state (the only state is inside the explicit ge_train_pipeline handle, see ge_train_steps).
  *
  * All pointers except where noted are DEVICE pointers (e.g. torch.Tensor.data_ptr()).
  * `table` is the single shared entity+relation table of holE.py:263-264: row-major fp32 [N, d],
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE_VERSION 100 /* 0.1.0 */
+#define GE_VERSION 200 /* 0.2.0 */
 
 /* argument errors (negative, -errno style) */
 #define GE_EINVAL (-22)  /* bad dimension / null pointer / misaligned buffer */
@@ -160,39 +161,62 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * reference's shuffle queue never yields a short batch, holE.py:283); negatives from
  * ge_corrupt_batch with step = global_step0 + s; lr_s = lr0 / (1 + decay_rate * (global_step0+s) /
  * decay_steps) (tf.train.inverse_time_decay, holE.py:292-294; decay_steps <= 0 keeps lr0); then one
- * ge_*_hinge_step.  No host synchronisation; every launch goes to `stream` in order.
- * workspace: >= ge_train_workspace_bytes(B, d) (it holds a ring of gradient-row regions, one per step in turn,
- * so that a region is not rewritten while its lines still sit in another XCD's L2) enables the prepared path for B <= 4096 (negatives and
- * a row-sorted gradient-slot index for 32 steps at a time are built by one LDS bitonic-sort launch;
- * the update then touches every distinct row once, without atomics unless a row has > 16
- * occurrences); with only ge_hinge_step_workspace_bytes the loop falls back to sampler + atomics.
- * The prepared path is the ONE place where the library keeps state behind the caller's back: per device
- * a non-blocking side stream and four events (created on first use, never freed), on which the prepare
- * launches for steps s+32.. run while `stream` executes steps s..; the two streams are ordered by events
- * only, the host is never blocked.  Calls on the same device from several host threads must be
- * serialised by the caller (as with the reference's init.so, init.cpp:145-150).
- * neg_ws: device [B,3] int32 scratch (holds the last step's negatives on return).  loss: device [n_steps*B] when keep_all_losses, else [B]
- * (last step).  model: 0 ComplEx, 1 HolE.
- * ev_pairs (nullable, HOST array of 2*n_steps events from ge_event_create): events are recorded on
- * `stream` immediately before and after kernel `ev_kernel` of every step (0 = sampler,
- * 1 = gather+score+hinge+grad, 2 = scatter-add) -- the hook bench.py uses to time one kernel. */
+ * ge_*_hinge_step.  No host synchronisation.
+ *
+ * workspace >= ge_train_workspace_bytes(B, d) enables the PREPARED path: the negatives and a
+ * row-sorted index of the step's gradient slots are built ahead of time, for a chunk of steps per
+ * launch (one workgroup per step and per sub-batch of 4096 pairs: sampler + stable LDS radix sort by
+ * row), into two chunk buffers inside the workspace.  The update then touches every distinct row
+ * once, with plain read-modify-writes (float atomics only for rows with > 16 gradient slots in a
+ * step and, when B > 4096, for all rows: sub-batches may share rows).  The workspace also holds a
+ * ring of gradient-row regions, one per step in turn.  With only ge_hinge_step_workspace_bytes the
+ * loop falls back to sampler + float-atomic scatter per step.
+ *
+ * pipeline (nullable): a handle from ge_train_pipeline_create, bound to the device that was current
+ * at creation.  It owns a non-blocking side stream and four events on which the prepare launch for
+ * the NEXT chunk of steps runs while `stream` executes the current one -- across calls too: when a
+ * call continues exactly where the previous call with the same handle stopped (same arrays, sizes,
+ * seed, mode, workspace; global_step0 and first_row advanced by the steps already run) its records
+ * are already built and nothing but the two per-step kernels is on the critical path.  Any other
+ * call restarts the sequence (its first prepare launch, ~20 us, is then exposed).  While a handle
+ * is live the caller must not modify `triples`, the type tables or the workspace between calls
+ * without ge_train_pipeline_reset; the streams are ordered by events only, the host never blocks,
+ * and before returning every call makes `stream` wait for the look-ahead launch, so work enqueued
+ * on `stream` afterwards (e.g. a stream-ordered free of the workspace) is ordered after it.  One
+ * handle must not be used from two host threads at once.  pipeline = NULL: the prepare launches go
+ * to `stream` itself and the library keeps no state whatsoever.
+ *
+ * neg_ws: device [B,3] int32 scratch (holds the last step's negatives on return).  loss: device
+ * [n_steps*B] when keep_all_losses, else [B] (last step).  model: 0 ComplEx, 1 HolE.
+ * ev_pairs (nullable, HOST array of 2*n_steps events from ge_event_create): the events ride on the
+ * dispatch of kernel `ev_kernel` of every step (1 = gather+score+hinge+grad, 2 = row update; 0 =
+ * the per-step sampler of the fallback path) and report that kernel's own begin/end -- the hook
+ * bench.py uses to time one kernel; NULL entries skip a step. */
 size_t ge_train_workspace_bytes(int64_t B, int32_t d);
-/* Selects how the prepared path executes a ComplEx step.  0 (default) = two launches per step:
- * gradients (rows with a single gradient slot in the step are updated right there by the pair that
- * owns the slot), then the row-sorted apply.  1 (opt-in, or env GE_FUSED_STEP=1) = ONE launch per
- * step: every pair publishes its gradient rows write-through (sc1), drains, and bumps per-row
- * arrival counters; the last arriver of a row sums and applies it ("last arriver executes": no grid
- * barrier, no spin; bitwise-reproducible incl. hot rows, bitwise-equal to mode 0 on rows with <= 16
- * occurrences).  Mode 1 is validated but measured slower at B=4096 (36 vs 22 us/step: the chain
- * through the hottest rows is serial), so it is not the default.  Returns the previous setting. */
-int ge_set_fused_step(int on);
+int ge_train_pipeline_create(void** pipeline);
+int ge_train_pipeline_reset(void* pipeline);
+int ge_train_pipeline_destroy(void* pipeline); /* waits for the side stream, then frees */
 int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T,
                    int64_t first_row, int64_t B, int64_t n_steps, const int32_t* id_to_type,
                    const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,
                    uint64_t seed, uint64_t global_step0, int32_t padded_size, int32_t mode,
                    float margin, float lr0, float decay_steps, float decay_rate, float max_norm,
                    int model, float* loss, int keep_all_losses, int32_t* neg_ws, void* workspace,
-                   size_t workspace_bytes, void** ev_pairs, int ev_kernel, void* stream);
+                   size_t workspace_bytes, void** ev_pairs, int ev_kernel, void* pipeline, void* stream);
+
+/* The prepare launch on its own: the records of n_steps consecutive steps, as ge_train_steps builds
+ * them, into `out` (>= n_steps * layout[0] int32 words).  ge_train_prepared_layout fills out8 =
+ * {words per step record, sub-batches per step, pairs per sub-batch S, offset of slot_item[6B],
+ * offset of sub-batch 0, words per sub-batch, offset of items inside a sub-batch, offset of islots}.
+ * A step record is  neg[3B] | slot_item[6B] | sub-batches { n_items, pad | items[4S][2] = {table row,
+ * count | multi << 30} | islots[4S][16] = the IndexedSlices slots (6*pair + k) an item sums, -1 padded }.
+ * direct = 1 (needs B <= 4096): a row with exactly one gradient slot in the step is not queued as an
+ * item; its slot is tagged -2 in slot_item and the pair that produces it updates the table row. */
+int ge_train_prepared_layout(int64_t B, int64_t* out8);
+int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t n_steps,
+                           const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
+                           const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
+                           int32_t mode, int direct, int32_t* out, size_t out_bytes, void* stream);
 
 /* --- thin wrappers over hipEvent_t so a ctypes host can time kernels on the launch stream. */
 int ge_event_create(void** ev);

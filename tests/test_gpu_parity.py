@@ -529,61 +529,108 @@ def test_bernoulli_sampler_bit_exact_vs_pinned_oracle(H):
     assert not any(tuple(int(v) for v in row) in known for row in neg[ok])
 
 
-# ---------------------------------------------------------------- fused single-launch step ("last arriver executes")
-def _set_fused(on):
-    from graphembeddings_amd import _lib
-    return _lib.load().ge_set_fused_step(int(on))
+# ---------------------------------------------------------------- the prepare launch on its own
+@pytest.mark.parametrize("B,N_extra,direct,mode", [(4096, 0, True, 0), (1000, 0, True, 1), (37, 0, False, 2),
+                                                   (4096, 1_200_000, True, 0), (8192, 0, False, 0), (300, 70_000, True, 3)])
+def test_prepared_records_equal_numpy_model(H, B, N_extra, direct, mode):
+    """ge_train_prepare_steps (sampler + stable LDS radix sort by row + work-item cut) against a NumPy
+    model of the same record, word for word: negatives (C oracle), the slots tagged for direct update,
+    every item's (row, count, multi) and slot list in (row, slot) order.  Covers 2 radix passes (FB15k
+    rows) and 3 (1.2 M rows), partial sub-batches, 2 sub-batches (B = 8192), unknown-type rows (-1)."""
+    from graphembeddings_amd import data as D
+    import prep_model as PM
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    N = fb.entity_count + N_extra
+    if N_extra:   # a table far larger than the typed id space: rows beyond it have no type (-1)
+        id_to_type = np.concatenate([id_to_type, np.full(N_extra, -1, np.int32)])
+    tri = D.synthetic_fb15k_triples(fb, n_triples=3 * B + 50, seed=5)
+    if N_extra:
+        idx = np.arange(0, len(tri), 2)                       # half the tails live in the high rows
+        tri[idx, 1] = np.random.default_rng(3).integers(fb.entity_count, N, len(idx))
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    lay = H.prepared_layout(B)
+    steps = 3
+    rec = H.prepare_steps(dev(tri), tt, B, steps, first_row=B + 7, seed=99, global_step=41, mode=mode, direct=direct).cpu().numpy()
+    T = len(tri)
+    row = B + 7
+    for s in range(steps):
+        if row + B > T:
+            row = 0
+        pos = tri[row:row + B]
+        neg = CO.corrupt_batch(pos, id_to_type, offsets, ids, 99, 41 + s, 1024, mode)
+        got = PM.parse_record(rec[s], B, lay)
+        exp = PM.expected_record(pos, neg, N, direct, lay)
+        assert np.array_equal(got["neg"], neg), s
+        assert got["n_items"] == exp["n_items"], (s, got["n_items"], exp["n_items"])
+        for sub in range(lay[1]):
+            assert np.array_equal(got["items"][sub], exp["items"][sub]), (s, sub)
+            assert np.array_equal(got["islots"][sub], exp["islots"][sub]), (s, sub)
+        if direct:
+            assert np.array_equal(got["slot_item"], exp["slot_item"]), s
+        row += B
 
 
-def test_fused_step_is_bitwise_equal_to_two_kernel_path_on_uniform_ids(H):
-    """Rows with <= 16 occurrences per step are summed in the same slot order by both paths: over
-    hundreds of dependent steps any stale or torn hand-off would break bitwise equality."""
-    rng = np.random.default_rng(1)
-    N, d, B, T = 60000, 200, 4096, 200000
-    tri = np.stack([rng.integers(0, N, T), rng.integers(0, N, T), rng.integers(0, N, T)], 1).astype(np.int32)
-    tt = H.TypeTables.from_host(np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32),
-                                padded_size=0)
-    base = dev((rng.standard_normal((N, d)) * 0.08).astype(np.float32))
-    outs, losses = [], []
-    try:
-        for fused in (1, 0, 1):
-            _set_fused(fused)
-            emb = base.clone()
-            tr = H.Trainer(emb, dev(tri), tt, B, seed=5, learning_rate=0.05, decay_steps=100.0)
-            l = tr.run(300, keep_losses=True)
-            torch.cuda.synchronize()
-            outs.append(emb)
-            losses.append(l)
-    finally:
-        _set_fused(0)
-    assert torch.equal(losses[0], losses[1]) and torch.equal(outs[0], outs[1])   # fused == two-kernel
-    assert torch.equal(outs[0], outs[2])                                          # and reproducible
-
-
-def test_fused_step_with_hot_rows_is_reproducible_and_matches(H):
-    """FB15k-shaped Zipfian batch: rows with hundreds of occurrences take the two-level (partial sums,
-    fixed item order) route -> two fused runs are bitwise identical, and they agree with the
-    two-kernel path (which combines hot rows with float atomics) to fp32 reordering noise."""
+def test_train_steps_large_batch_and_fallback_branch(H):
+    """B = 8192 (two sort sub-batches per step, row updates combined atomically) and the fallback branch
+    of ge_train_steps (workspace without room for prepared records: per-step sampler + float-atomic
+    scatter) both reproduce the C port's loop."""
     from graphembeddings_amd import data as D
     fb = D.fb15k_shape()
     names, id_to_type, offsets, ids = fb.type_arrays()
+    B, d, steps = 8192, 64, 4
+    tri = D.synthetic_fb15k_triples(fb, n_triples=3 * B + 11, seed=13)
+    table = O.init_table(fb.entity_count, d, seed=6)
+    table[::5] *= 6.0
     tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
-    tri = dev(D.synthetic_fb15k_triples(fb, n_triples=100000, seed=2))
-    base = H.init_embeddings(fb.entity_count, 200, seed=1)
-    outs = []
-    try:
-        for fused in (1, 1, 0):
-            _set_fused(fused)
-            emb = base.clone()
-            tr = H.Trainer(emb, tri, tt, 4096, seed=9, learning_rate=0.1, decay_steps=500.0)
-            tr.run(150)
-            torch.cuda.synchronize()
-            outs.append(emb)
-    finally:
-        _set_fused(0)
-    assert torch.equal(outs[0], outs[1])
-    assert (outs[0] - outs[2]).abs().max().item() < 2e-5
-    assert torch.isfinite(outs[0]).all()
+    ctab = table.copy()
+    closs = []
+    row = 0
+    for s in range(steps):
+        if row + B > len(tri):
+            row = 0
+        pos = tri[row:row + B]
+        neg = CO.corrupt_batch(pos, id_to_type, offsets, ids, 4, s, 1024, 0)
+        closs.append(CO.hinge_step(ctab, pos, neg, 0.2, 0.1, threads=8))
+        row += B
+    for prepared in (True, False):
+        emb = dev(table).clone()
+        tr = H.Trainer(emb, dev(tri), tt, B, margin=0.2, learning_rate=0.1, seed=4, prepared=prepared)
+        losses = tr.run(steps, keep_losses=True).cpu().numpy()
+        for s in range(steps):
+            assert np.abs(losses[s] - closs[s]).max() < 2e-5, (prepared, s)
+        assert np.abs(emb.cpu().numpy() - ctab).max() < 1e-4, prepared
+        assert np.array_equal(tr._neg.cpu().numpy(), neg)
+        tr.close()
+
+
+def test_train_steps_lookahead_survives_between_calls(H):
+    """The records prepared ahead on the pipeline's side stream are reused by the call that continues the
+    sequence: many short calls (7 steps, train.py's tick at FB15k / B=4096), a reset in the middle, a
+    call without a pipeline handle and one long call give bitwise-identical tables and losses."""
+    rng = np.random.default_rng(2)
+    N, d, B, T = 30000, 200, 1024, 50000
+    tri = np.stack([rng.integers(10, N, T), rng.integers(10, N, T), rng.integers(10, N, T)], 1).astype(np.int32)
+    tt = H.TypeTables.from_host(np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32),
+                                padded_size=0)
+    base = dev((rng.standard_normal((N, d)) * 0.05).astype(np.float32))
+    outs, losses = [], []
+    for variant in ("one", "sevens", "sevens_reset", "no_handle"):
+        emb = base.clone()
+        tr = H.Trainer(emb, dev(tri), tt, B, seed=8, lookahead=(variant != "no_handle"))
+        if variant == "one":
+            last = tr.run(105)
+        else:
+            for k in range(15):
+                if variant == "sevens_reset" and k == 6:
+                    tr.invalidate()
+                last = tr.run(7)
+        torch.cuda.synchronize()
+        outs.append(emb)
+        losses.append(last.clone())
+        tr.close()
+    for o, l in zip(outs[1:], losses[1:]):
+        assert torch.equal(outs[0], o) and torch.equal(losses[0], l)
 
 
 def test_score_candidates_large_tiles_path(H):
