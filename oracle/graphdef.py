@@ -69,7 +69,7 @@ def parse_pbtxt(path: str) -> dict:
 
 def _tensor(t: dict):
     dt = t["dtype"][0]
-    dims = [d["size"][0] for d in t.get("tensor_shape", [{}])[0].get("dim", [])]
+    dims = [d.get("size", [0])[0] for d in t.get("tensor_shape", [{}])[0].get("dim", [])]   # absent = proto default 0
     n = int(np.prod(dims)) if dims else 1
     if "tensor_content" in t:
         arr = np.frombuffer(t["tensor_content"][0], dtype=_RAW[dt]).astype(_DT[dt])
@@ -78,9 +78,11 @@ def _tensor(t: dict):
     else:
         key = {"DT_FLOAT": "float_val", "DT_DOUBLE": "double_val", "DT_INT32": "int_val", "DT_INT64": "int64_val",
                "DT_BOOL": "bool_val"}[dt]
-        vals = t.get(key, [0])
+        vals = t.get(key, [0] if n else [])
         arr = np.array(vals, dtype=_DT[dt])
-        if arr.size == 1 and n != 1:
+        if n == 0:
+            arr = arr[:0]
+        elif arr.size == 1 and n != 1:
             arr = np.full(n, arr[0], dtype=_DT[dt])                         # splat encoding
     return arr.reshape(dims)
 

@@ -12,18 +12,28 @@ A restatement, function by function, of the arithmetic of
 type-safe corruption sampler, the LR schedule and the rank/MRR evaluator.
 Each function cites the reference lines it follows.
 
-Pinning status: **PARITY UNPINNED by reference tests.**
-The reference has no tests, no golden vectors and cannot be executed here
-(TensorFlow 1.2 is not installed).  The only reference-held
-known answers that exist are pinned in tests/test_oracle.py:
+Pinning status: **PINNED against the reference's own recorded training graph for everything around
+the score; the ComplEx / README-HolE score lines themselves are restatements.**
+The reference has no tests and cannot be executed here (TensorFlow 1.2 is not installed; SURVEY.md
+section 8c), but it ships what TensorFlow built from holE.py: holE-20170724/graph.pbtxt, the complete
+training GraphDef (forward, TensorFlow's autodiff sub-graph, IndexedSlices concat, ScatterSub).
+oracle/graphdef.py reads that file and EXECUTES its nodes with NumPy; tests/golden/graphdef_v1.npz
+holds the outputs for seeded inputs (generator: tests/golden/make_graphdef_golden.py) and
+tests/test_graphdef_pins.py requires this module's model="graph20170724" -- the graph's historical
+score (complex FFT correlation, Sum(Re+Im), tanh) on top of the SAME clip_scale / _clip_backward /
+hinge mask / slot order / sgd_step helpers the ComplEx and HolE models use -- to reproduce the loss
+vector, the IndexedSlices and the table after the ScatterSub to 1e-12, including the |x| == max_norm
+tie, pre-activation == 0 ties, inactive pairs and heavy index duplication.  What that does NOT
+cover: the four-op ComplEx score of today's holE.py:191-192 (Mul, Conj, Real, Sum) and the sigmoid
+(holE.py:198), which no recorded graph contains; they are checked against torch autograd only.
+One decided deviation found this way: an ALL-ZERO row makes the recorded graph emit NaN (RsqrtGrad
+multiplies MinimumGrad's zero by rsqrt(0)^3 = inf); here the inactive branch contributes exactly 0.
+Other reference-held known answers pinned in tests/test_oracle.py:
   * the Xavier-normal stddev constants stored in the two committed graph
     dumps (holE-20170714/graph.pbtxt, holE-20170724/graph.pbtxt),
   * the inverse-time-decay constants of holE-20170714/graph.pbtxt,
   * the FB15k id files (triples-valid.txt == the raw Freebase valid split
     mapped through the id files, order (head, tail, relation)).
-Everything else is checked against an independent second implementation
-(torch CPU autograd over the same op chain) -- an independent opinion, not the
-reference.
 
 Third-party arithmetic: TensorFlow (un-vendored, unpinned; graph producer 22
 / "1.2.1" per the committed meta-graphs).  Op semantics restated here:
@@ -231,6 +241,20 @@ def _side_grads(triples, table, coef, max_norm, model):
         gh = np.concatenate([c * e + dd * f, c * f - dd * e], axis=1)
         gt = np.concatenate([a * c - b * dd, a * dd + b * c], axis=1)
         gr = np.concatenate([a * e + b * f, a * f - b * e], axis=1)
+    elif model == "graph20170724":
+        # the HISTORICAL variant recorded in holE-20170724/graph.pbtxt:6221-6521 (see
+        # hole_graph20170724_evaluate): s = sum_m (Re + Im)(r_m c_m) = Re((1-i) sum_m r_m c_m),
+        # c_m = sum_i conj(h_i) t_{i+m}.  With g = ds/dRe + i ds/dIm per complex component:
+        #   g_r = conj((1-i) c),  g_t = (1+i) (conj(r) (*) h)  [circular convolution],
+        #   g_h = (1-i) sum_m r_m t_{i+m}.
+        k = d // 2
+        ch, ct, cr = (v[:, :k] + 1j * v[:, k:] for v in (yh, yt, yr))
+        al = 1.0 - 1.0j
+        fh, ft, fcr = np.fft.fft(ch, axis=1), np.fft.fft(ct, axis=1), np.fft.fft(np.conj(cr), axis=1)
+        g_r = np.conj(al * np.fft.ifft(np.conj(fh) * ft, axis=1))
+        g_t = np.conj(al) * np.fft.ifft(fcr * fh, axis=1)
+        g_h = al * np.fft.ifft(np.conj(fcr) * ft, axis=1)
+        gh, gt, gr = (np.concatenate([g.real, g.imag], axis=1) for g in (g_h, g_t, g_r))
     else:  # hole
         fh, ft, fr = (np.fft.fft(v, axis=1) for v in (yh, yt, yr))
         # s = sum_k r_k sum_i h_i t_{i+k}
@@ -253,13 +277,18 @@ def hinge_grads(pos, neg, table, margin: float = 0.2, max_norm: float = 1.0,
     c+_i = m_i sigma'(s+),  c-_i = -m_i sigma'(s-).
     """
     pos, neg = np.asarray(pos), np.asarray(neg)
-    sfun = complex_score if model == "complex" else hole_score
-    sp, sn = sigmoid(sfun(pos, table, max_norm)), sigmoid(sfun(neg, table, max_norm))
+    if model == "graph20170724":     # tanh activation (holE-20170724/graph.pbtxt:6520), same hinge around it
+        sp, sn = hole_graph20170724_evaluate(pos, table, max_norm)[:, 0], hole_graph20170724_evaluate(neg, table, max_norm)[:, 0]
+        dsp, dsn = 1 - sp * sp, 1 - sn * sn
+    else:
+        sfun = complex_score if model == "complex" else hole_score
+        sp, sn = sigmoid(sfun(pos, table, max_norm)), sigmoid(sfun(neg, table, max_norm))
+        dsp, dsn = sp * (1 - sp), sn * (1 - sn)
     pre = sp - sn + margin
     m = (pre >= 0).astype(table.dtype)
     loss = np.maximum(pre, 0.0)
-    ghp, gtp, grp = _side_grads(pos, table, m * sp * (1 - sp), max_norm, model)
-    ghn, gtn, grn = _side_grads(neg, table, -m * sn * (1 - sn), max_norm, model)
+    ghp, gtp, grp = _side_grads(pos, table, m * dsp, max_norm, model)
+    ghn, gtn, grn = _side_grads(neg, table, -m * dsn, max_norm, model)
     idx = np.concatenate([pos[:, 2], neg[:, 2], pos[:, 1], neg[:, 1], pos[:, 0], neg[:, 0]])
     val = np.concatenate([grp, grn, gtp, gtn, ghp, ghn], axis=0)
     return idx, val, loss
