@@ -22,6 +22,9 @@ SYMBOLS = {
     "ge_max_dim": (C.c_int, []),
     "ge_complex_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
     "ge_hole_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
+    "ge_hole_to_spectral": (C.c_int, [_p, _i64, _i32, _p]),
+    "ge_hole_from_spectral": (C.c_int, [_p, _i64, _i32, _p]),
+    "ge_hole_spectral_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
     "ge_hinge_loss": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, C.c_int, _p, _p, _p]),
     "ge_hinge_step_workspace_bytes": (_sz, [_i64, _i32]),
     "ge_complex_hinge_step": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),

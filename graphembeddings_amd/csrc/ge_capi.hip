@@ -4,10 +4,11 @@
 #include "ge_common.h"
 
 namespace ge {
-int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
-int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr);
+int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t, int spectral = 0);
+int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t, int spectral = 0);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
 int complex_max_dim();
+int hole_spectral_launch(float*, int64_t, int32_t, int, hipStream_t);
 int hole_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
 int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
@@ -57,23 +58,42 @@ int ge_hole_score(const float* table, int64_t N, int32_t d, const int32_t* tripl
   return hole_score_launch(table, N, d, triples, B, max_norm, apply_sigmoid, out, (hipStream_t)stream);
 }
 
+int ge_hole_to_spectral(float* table, int64_t N, int32_t d, void* stream) {
+  if (!ok_table(table, N, d)) return GE_EINVAL;
+  return hole_spectral_launch(table, N, d, 0, (hipStream_t)stream);
+}
+
+int ge_hole_from_spectral(float* table, int64_t N, int32_t d, void* stream) {
+  if (!ok_table(table, N, d)) return GE_EINVAL;
+  return hole_spectral_launch(table, N, d, 1, (hipStream_t)stream);
+}
+
+int ge_hole_spectral_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                           float max_norm, int apply_sigmoid, float* out, void* stream) {
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (B > 0 && (!triples || !out)) return GE_EINVAL;
+  return complex_score_launch(table, N, d, triples, B, max_norm, apply_sigmoid, out, (hipStream_t)stream, 1);
+}
+
 int ge_hinge_loss(const float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
                   int64_t B, float margin, float max_norm, int model, float* loss, float* sig_out,
                   void* stream) {
-  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm) || (model != 0 && model != 1)) return GE_EINVAL;
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm) || model < 0 || model > 2) return GE_EINVAL;
   if (B > 0 && (!pos || !neg || !loss)) return GE_EINVAL;
-  if (model == 0)
-    return complex_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream);
+  if (model != GE_MODEL_HOLE)
+    return complex_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream,
+                                     model == GE_MODEL_HOLE_SPECTRAL);
   return hole_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream);
 }
 
 int ge_hinge_grad(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
                   int64_t B, float margin, float lr, float max_norm, int model, float* loss,
                   int32_t* grad_idx, float* grad_val, void* stream) {
-  if (B < 0 || !ok_table(rows, N, d) || !max_norm_ok(max_norm) || (model != 0 && model != 1)) return GE_EINVAL;
+  if (B < 0 || !ok_table(rows, N, d) || !max_norm_ok(max_norm) || model < 0 || model > 2) return GE_EINVAL;
   if (B > 0 && (!pos || !neg || !loss || !grad_idx || !grad_val)) return GE_EINVAL;
-  if (model == 0)
-    return complex_hinge_grad_launch(rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, (hipStream_t)stream);
+  if (model != GE_MODEL_HOLE)
+    return complex_hinge_grad_launch(rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, (hipStream_t)stream,
+                                     nullptr, nullptr, nullptr, nullptr, model == GE_MODEL_HOLE_SPECTRAL);
   return hole_hinge_grad_launch(rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, (hipStream_t)stream);
 }
 
@@ -177,7 +197,8 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
   if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm))
     return GE_EINVAL;
   if (!triples || !id_to_type || !type_offsets || !type_ids || !loss || !neg_ws || !workspace) return GE_EINVAL;
-  if (model != 0 && model != 1) return GE_EINVAL;
+  if (model < 0 || model > 3) return GE_EINVAL;
+  if (model == GE_MODEL_HOLE_SPECTRAL && (d & 1)) return GE_EINVAL;
   if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
   if (workspace_bytes < ge_hinge_step_workspace_bytes(B, d)) return GE_ENOMEM;
   if (ev_pairs && (ev_kernel < 0 || ev_kernel > 2)) return GE_EINVAL;

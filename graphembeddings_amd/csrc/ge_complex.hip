@@ -20,7 +20,7 @@
 namespace ge {
 
 // ---------------------------------------------------------------- evaluate_triples
-template <int VEC, int LPT, int NITER>
+template <bool SPEC, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_score_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ triples, int64_t B,
     float max_norm, int apply_sigmoid, float* __restrict__ out) {
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kBlock) void complex_score_kernel(
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int k = d >> 1, nvec = k / VEC;
+  const float wscale = 1.0f / (float)d;   // SPEC only: Parseval / correlation-theorem factor
   for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
     const int64_t g = base + grp;
     const bool live = g < B;
@@ -40,13 +41,13 @@ __global__ __launch_bounds__(kBlock) void complex_score_kernel(
     load_row<VEC, LPT, NITER>(table, hi, d, k, nvec, sub, h);
     load_row<VEC, LPT, NITER>(table, ti, d, k, nvec, sub, t);
     load_row<VEC, LPT, NITER>(table, ri, d, k, nvec, sub, r);
-    const SideFwd f = side_forward<VEC, LPT, NITER>(h, t, r, max_norm);
+    const SideFwd f = side_forward<SPEC, VEC, LPT, NITER>(h, t, r, max_norm, sub == 0, wscale);
     if (live && sub == 0) out[g] = bad ? __builtin_nanf("") : (apply_sigmoid ? f.sig : f.s);
   }
 }
 
 // ---------------------------------------------------------------- evaluate_batch (forward only)
-template <int VEC, int LPT, int NITER>
+template <bool SPEC, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float max_norm,
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int k = d >> 1, nvec = k / VEC;
+  const float wscale = 1.0f / (float)d;   // SPEC only: Parseval / correlation-theorem factor
   for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
     const int64_t g = base + grp;
     const bool live = g < B;
@@ -70,11 +72,11 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
     load_row<VEC, LPT, NITER>(table, p[0], d, k, nvec, sub, h);
     load_row<VEC, LPT, NITER>(table, p[1], d, k, nvec, sub, t);
     load_row<VEC, LPT, NITER>(table, p[2], d, k, nvec, sub, r);
-    const SideFwd fp = side_forward<VEC, LPT, NITER>(h, t, r, max_norm);
+    const SideFwd fp = side_forward<SPEC, VEC, LPT, NITER>(h, t, r, max_norm, sub == 0, wscale);
     load_row<VEC, LPT, NITER>(table, n[0], d, k, nvec, sub, h);
     load_row<VEC, LPT, NITER>(table, n[1], d, k, nvec, sub, t);
     load_row<VEC, LPT, NITER>(table, n[2], d, k, nvec, sub, r);
-    const SideFwd fn = side_forward<VEC, LPT, NITER>(h, t, r, max_norm);
+    const SideFwd fn = side_forward<SPEC, VEC, LPT, NITER>(h, t, r, max_norm, sub == 0, wscale);
     if (live && sub == 0) {
       const float nanv = __builtin_nanf("");
       loss[g] = bad ? nanv : fmaxf(fp.sig - fn.sig + margin, 0.f);  // holE.py:231
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
 // h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
 // rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
-template <int VEC, int LPT, int NITER>
+template <bool SPEC, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int k = d >> 1, nvec = k / VEC;
+  const float wscale = 1.0f / (float)d;   // SPEC only: Parseval / correlation-theorem factor
   const float neg_lr = -lr;
   for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
     const int64_t g = base + grp;
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, xp[X]);
 #pragma unroll
     for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, n[X], d, k, nvec, sub, xn[X]);
-    const SideFwd fp = side_forward<VEC, LPT, NITER>(xp[0], xp[1], xp[2], max_norm);
-    const SideFwd fn = side_forward<VEC, LPT, NITER>(xn[0], xn[1], xn[2], max_norm);
+    const SideFwd fp = side_forward<SPEC, VEC, LPT, NITER>(xp[0], xp[1], xp[2], max_norm, sub == 0, wscale);
+    const SideFwd fn = side_forward<SPEC, VEC, LPT, NITER>(xn[0], xn[1], xn[2], max_norm, sub == 0, wscale);
     const float pre = fp.sig - fn.sig + margin;
     const bool on = live && !bad && (pre >= 0.f);  // MaximumGrad: x >= y
     if (live && sub == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
@@ -149,10 +152,10 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           float gre, gim;
-          graw<VEC, NITER>(X, xp[0], xp[1], xp[2], it, v, gre, gim);
+          graw<SPEC, VEC, NITER>(X, xp[0], xp[1], xp[2], it, v, sub == 0, gre, gim);
           pre_[v] = kp.alpha * gre + kp.beta * xp[X].re[it][v];
           pim_[v] = kp.alpha * gim + kp.beta * xp[X].im[it][v];
-          graw<VEC, NITER>(X, xn[0], xn[1], xn[2], it, v, gre, gim);
+          graw<SPEC, VEC, NITER>(X, xn[0], xn[1], xn[2], it, v, sub == 0, gre, gim);
           nre_[v] = kn.alpha * gre + kn.beta * xn[X].re[it][v];
           nim_[v] = kn.alpha * gim + kn.beta * xn[X].im[it][v];
         }
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void complex_logloss_grad_kernel(
     Row<VEC, NITER> x[3];
 #pragma unroll
     for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, x[X]);
-    const SideFwd f = side_forward<VEC, LPT, NITER>(x[0], x[1], x[2], max_norm);
+    const SideFwd f = side_forward<false, VEC, LPT, NITER>(x[0], x[1], x[2], max_norm, false, 1.f);
     const float z = -y * f.s;                                            // holE.py:195
     const float softplus = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
     const float coef = -y * sigmoidf_dev(z);                             // d/ds log(1+exp(-y s))
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void complex_logloss_grad_kernel(
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           float gre, gim;
-          graw<VEC, NITER>(X, x[0], x[1], x[2], it, v, gre, gim);
+          graw<false, VEC, NITER>(X, x[0], x[1], x[2], it, v, false, gre, gim);
           re_[v] = kc.alpha * gre + kc.beta * x[X].re[it][v];
           im_[v] = kc.alpha * gim + kc.beta * x[X].im[it][v];
         }
@@ -304,31 +307,38 @@ static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
     }                                                                                  \
   } while (0)
 
+// SP (the SPEC template argument) is bound per branch; CALL mentions it
+#define GE_DISPATCH_SPEC(FLAG, S, CALL)                                                \
+  do {                                                                                 \
+    if (FLAG) { constexpr bool SP = true; GE_DISPATCH_SHAPE(S, 2, CALL); }             \
+    else { constexpr bool SP = false; GE_DISPATCH_SHAPE(S, 2, CALL); }                 \
+  } while (0)
+
 int complex_score_launch(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
-                         float max_norm, int apply_sigmoid, float* out, hipStream_t st) {
+                         float max_norm, int apply_sigmoid, float* out, hipStream_t st, int spectral) {
   Shape s;
   if (!pick_shape(d, table, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   if (B == 0) return 0;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipLaunchKernelGGL((complex_score_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out)
-  GE_DISPATCH_SHAPE(s, 2, CALL);
+  hipLaunchKernelGGL((complex_score_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out)
+  GE_DISPATCH_SPEC(spectral, s, CALL);
 #undef CALL
   return launch_status();
 }
 
 int complex_hinge_loss_launch(const float* table, int64_t N, int32_t d, const int32_t* pos,
                               const int32_t* neg, int64_t B, float margin, float max_norm, float* loss,
-                              float* sig_out, hipStream_t st) {
+                              float* sig_out, hipStream_t st, int spectral) {
   Shape s;
   if (!pick_shape(d, table, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   if (B == 0) return 0;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipLaunchKernelGGL((complex_hinge_loss_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, pos, neg, B, margin, max_norm, loss, sig_out)
-  GE_DISPATCH_SHAPE(s, 2, CALL);
+  hipLaunchKernelGGL((complex_hinge_loss_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, pos, neg, B, margin, max_norm, loss, sig_out)
+  GE_DISPATCH_SPEC(spectral, s, CALL);
 #undef CALL
   return launch_status();
 }
@@ -336,7 +346,8 @@ int complex_hinge_loss_launch(const float* table, int64_t N, int32_t d, const in
 int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* pos,
                               const int32_t* neg, int64_t B, float margin, float lr, float max_norm,
                               float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st,
-                              hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* slot_item, float* table_rw) {
+                              hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* slot_item, float* table_rw,
+                              int spectral) {
   Shape s;
   if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   // the gradient rows are written with the same vector width: grad_val must be as aligned as rows
@@ -346,8 +357,8 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw)
-  GE_DISPATCH_SHAPE(s, 2, CALL);
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw)
+  GE_DISPATCH_SPEC(spectral, s, CALL);
 #undef CALL
   return launch_status();
 }

@@ -1,5 +1,16 @@
-// ge_complex_dev.h -- device helpers shared by the ComplEx kernels (ge_complex.hip, ge_fused.hip):
+// ge_complex_dev.h -- device helpers of the ComplEx-shaped kernels (ge_complex.hip):
 // lane-sliced rows, clip/score forward of one side, closed-form row-gradient coefficients.
+//
+// SPEC = true is the same arithmetic on a SPECTRAL HolE table (ge_hole_to_spectral): a row holds the
+// half spectrum of a real d-vector x, packed in d floats as [Re X_0 .. Re X_{k-1} | Re X_k, Im X_1 ..
+// Im X_{k-1}], k = d/2 (X_0 and the Nyquist bin X_k are real; X_k sits in the unused Im X_0 slot).
+// With Hermitian weights w_0 = w_k = 1, w_f = 2:
+//   |x|^2        = (1/d) sum_f w_f |X_f|^2                                   (Parseval)
+//   r . (h * t)  = (1/d) sum_f w_f Re(H_f R_f conj(T_f))                      (README.md:42, correlation theorem)
+// i.e. HolE IS the ComplEx trilinear form on the half spectrum; the DFT is linear, so clip (a per-row
+// scalar) and SGD commute with it, and the DFT of the real-domain row gradient is the UNWEIGHTED
+// complex gradient of that form (the factor d/w_f of the change of variables cancels the weight).
+// Lane sub = 0, element 0 holds the packed pair (X_0, X_k): two independent real dimensions.
 #pragma once
 #include "ge_common.h"
 
@@ -28,20 +39,25 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rows, int32_t
   }
 }
 
-template <int VEC, int NITER>
-__device__ __forceinline__ float row_sumsq(const Row<VEC, NITER>& R) {
+// `first` = this lane holds element 0 of the row (sub == 0): only meaningful for SPEC
+template <bool SPEC, int VEC, int NITER>
+__device__ __forceinline__ float row_sumsq(const Row<VEC, NITER>& R, bool first) {
   float ss = 0.f;
 #pragma unroll
   for (int it = 0; it < NITER; ++it)
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) ss += R.re[it][v] * R.re[it][v] + R.im[it][v] * R.im[it][v];
+    for (int v = 0; v < VEC; ++v) {
+      const float q = R.re[it][v] * R.re[it][v] + R.im[it][v] * R.im[it][v];
+      if (SPEC) ss += (it == 0 && v == 0 && first) ? q : 2.f * q;
+      else ss += q;
+    }
   return ss;
 }
 
 // lane-partial of sum_k Re(h_k r_k conj(t_k)) = a(ce+df) + b(cf-de)   (holE.py:191-192)
-template <int VEC, int NITER>
+template <bool SPEC, int VEC, int NITER>
 __device__ __forceinline__ float raw_score(const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
-                                           const Row<VEC, NITER>& r) {
+                                           const Row<VEC, NITER>& r, bool first) {
   float s = 0.f;
 #pragma unroll
   for (int it = 0; it < NITER; ++it)
@@ -49,7 +65,8 @@ __device__ __forceinline__ float raw_score(const Row<VEC, NITER>& h, const Row<V
     for (int v = 0; v < VEC; ++v) {
       const float a = h.re[it][v], b = h.im[it][v], e = t.re[it][v], f = t.im[it][v];
       const float c = r.re[it][v], dd = r.im[it][v];
-      s += a * (c * e + dd * f) + b * (c * f - dd * e);
+      if (SPEC) s += (it == 0 && v == 0 && first) ? (a * c * e + b * dd * f) : 2.f * (a * (c * e + dd * f) + b * (c * f - dd * e));
+      else s += a * (c * e + dd * f) + b * (c * f - dd * e);
     }
   return s;
 }
@@ -62,14 +79,17 @@ struct SideFwd {
   float s;                 // clipped score
 };
 
-template <int VEC, int LPT, int NITER>
+// wscale = 1 (ComplEx) or 1/d (SPEC: the Parseval / correlation-theorem factor)
+template <bool SPEC, int VEC, int LPT, int NITER>
 __device__ __forceinline__ SideFwd side_forward(const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
-                                                const Row<VEC, NITER>& r, float max_norm) {
+                                                const Row<VEC, NITER>& r, float max_norm, bool first,
+                                                float wscale) {
   SideFwd o;
-  const float ssh = group_sum<LPT>(row_sumsq(h));
-  const float sst = group_sum<LPT>(row_sumsq(t));
-  const float ssr = group_sum<LPT>(row_sumsq(r));
-  o.s_raw = group_sum<LPT>(raw_score(h, t, r));
+  float ssh = group_sum<LPT>(row_sumsq<SPEC>(h, first));
+  float sst = group_sum<LPT>(row_sumsq<SPEC>(t, first));
+  float ssr = group_sum<LPT>(row_sumsq<SPEC>(r, first));
+  o.s_raw = group_sum<LPT>(raw_score<SPEC>(h, t, r, first));
+  if (SPEC) { ssh *= wscale; sst *= wscale; ssr *= wscale; o.s_raw *= wscale; }
   o.sc[0] = clip_scale(ssh, max_norm, o.inv[0]);
   o.sc[1] = clip_scale(sst, max_norm, o.inv[1]);
   o.sc[2] = clip_scale(ssr, max_norm, o.inv[2]);
@@ -96,12 +116,19 @@ __device__ __forceinline__ RowCoef row_coef(float coef, const SideFwd& f, int X,
   return c;
 }
 
-// raw bilinear gradients of s_raw wrt X for one lane slice
-template <int VEC, int NITER>
+// raw bilinear gradients of s_raw wrt X for one lane slice (SPEC: the DFT of the real-domain gradient;
+// the packed element 0 is two real dimensions, each the plain product of the other two)
+template <bool SPEC, int VEC, int NITER>
 __device__ __forceinline__ void graw(int X, const Row<VEC, NITER>& h, const Row<VEC, NITER>& t,
-                                     const Row<VEC, NITER>& r, int it, int v, float& gre, float& gim) {
+                                     const Row<VEC, NITER>& r, int it, int v, bool first, float& gre, float& gim) {
   const float a = h.re[it][v], b = h.im[it][v], e = t.re[it][v], f = t.im[it][v];
   const float c = r.re[it][v], dd = r.im[it][v];
+  if (SPEC && it == 0 && v == 0 && first) {
+    if (X == 0) { gre = c * e; gim = dd * f; }
+    else if (X == 1) { gre = a * c; gim = b * dd; }
+    else { gre = a * e; gim = b * f; }
+    return;
+  }
   if (X == 0) { gre = c * e + dd * f; gim = c * f - dd * e; }        // d/dh
   else if (X == 1) { gre = a * c - b * dd; gim = a * dd + b * c; }   // d/dt
   else { gre = a * e + b * f; gim = a * f - b * e; }                 // d/dr

@@ -29,10 +29,11 @@
 
 namespace ge {
 
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
+int hole_spectral_launch(float*, int64_t, int32_t, int, hipStream_t);
 
 constexpr int kSlotDirect = -2;  // slot_item code: sole contributor of its row, applied by the producer
 constexpr int kPrepThreads = 1024;
@@ -491,6 +492,15 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
                     int32_t* neg_ws, void* workspace, size_t workspace_bytes, void** ev_pairs, int ev_kernel,
                     void* pipe_handle, hipStream_t st) {
   if (n_steps <= 0) return 0;
+  // HolE (model 1, the caller's real-valued table) is carried in the frequency domain for the duration
+  // of the call when d is even: the DFT is linear and norm-preserving, so the clip and SGD commute with
+  // it, and README.md:42's r . ifft(conj(fft h) fft t) is the ComplEx-shaped trilinear form on the half
+  // spectrum (ge_complex_dev.h, SPEC).  Model 2: the table already IS spectral (ge_hole_to_spectral).
+  // Model 3 (and odd d): the direct-correlation kernels of ge_hole.hip on the real table.
+  const bool transform = model == GE_MODEL_HOLE && !(d & 1);
+  const bool spectral = transform || model == GE_MODEL_HOLE_SPECTRAL;
+  const bool hole_direct = (model == GE_MODEL_HOLE && (d & 1)) || model == GE_MODEL_HOLE_DIRECT;
+  if (transform) { int rc = hole_spectral_launch(table, N, d, /*inverse=*/0, st); if (rc) return rc; }
   int32_t* gidx = reinterpret_cast<int32_t*>(workspace);
   float* gval0 = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256));
   const bool fast = train_fast_ok(B, d) && workspace_bytes >= train_ws_bytes(B, d);
@@ -500,7 +510,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
   const int64_t K = prep_chunk_steps(B);
   int32_t* prep_base = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + train_grad_bytes(B, d));
   const int64_t buf_ints = (int64_t)(prep_chunk_bytes(B) / sizeof(int32_t));
-  const int direct = (L.n_sub == 1 && model == 0) ? 1 : 0;   // sole-slot rows updated by the producing pair
+  const int direct = (L.n_sub == 1 && !hole_direct) ? 1 : 0;   // sole-slot rows updated by the producing pair
   Pipeline* pipe = fast ? static_cast<Pipeline*>(pipe_handle) : nullptr;
   Pipeline local;               // no handle: prepare on the caller's stream, nothing survives the call
   int64_t base_abs = 0;
@@ -592,9 +602,9 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     hipEvent_t g0 = ev_kernel == 1 ? e0 : nullptr, g1 = ev_kernel == 1 ? e1 : nullptr;
     hipEvent_t a0 = ev_kernel == 2 ? e0 : nullptr, a1 = ev_kernel == 2 ? e1 : nullptr;
     const bool dir = fast && direct;
-    rc = model == 1 ? hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1)
-                    : complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1,
-                                                dir ? step_rec + L.off_slot : nullptr, dir ? table : nullptr);
+    rc = hole_direct ? hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1)
+                     : complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1,
+                                                 dir ? step_rec + L.off_slot : nullptr, dir ? table : nullptr, spectral ? 1 : 0);
     if (rc) return rc;
     if (fast) rc = apply_sorted_launch(table, d, L, step_rec, gidx, gval, st, a0, a1);
     else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
@@ -612,6 +622,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
       pipe->next_abs = base_abs + n_steps;
     }
   }
+  if (transform) { int rc = hole_spectral_launch(table, N, d, /*inverse=*/1, st); if (rc) return rc; }
   return 0;
 }
 

@@ -18,8 +18,9 @@ import torch
 
 from . import _lib
 
-MODEL_COMPLEX, MODEL_HOLE = 0, 1
-_MODELS = {"complex": MODEL_COMPLEX, "hole": MODEL_HOLE, 0: 0, 1: 1}
+MODEL_COMPLEX, MODEL_HOLE, MODEL_HOLE_SPECTRAL, MODEL_HOLE_DIRECT = 0, 1, 2, 3
+_MODELS = {"complex": MODEL_COMPLEX, "hole": MODEL_HOLE, "hole_spectral": MODEL_HOLE_SPECTRAL,
+           "hole_direct": MODEL_HOLE_DIRECT, 0: 0, 1: 1, 2: 2, 3: 3}
 
 CORRUPT_BATCH_COIN, CORRUPT_ROW_COIN, CORRUPT_HEADS, CORRUPT_TAILS = 0, 1, 2, 3
 
@@ -74,10 +75,26 @@ def evaluate_triples(triple_batch: torch.Tensor, embeddings: torch.Tensor, label
     emb = _table(embeddings)
     tb = _triples(triple_batch)
     out = torch.empty(tb.shape[0], dtype=torch.float32, device=emb.device)
-    fn = "ge_complex_score" if _MODELS[model] == MODEL_COMPLEX else "ge_hole_score"
+    fn = {MODEL_COMPLEX: "ge_complex_score", MODEL_HOLE: "ge_hole_score", MODEL_HOLE_DIRECT: "ge_hole_score",
+          MODEL_HOLE_SPECTRAL: "ge_hole_spectral_score"}[_MODELS[model]]
     _lib.call(fn, emb.data_ptr(), emb.shape[0], emb.shape[1], tb.data_ptr(), tb.shape[0],
               max_norm, int(apply_sigmoid), out.data_ptr(), _stream())
     return out.view(-1, 1)
+
+
+def hole_to_spectral(embeddings: torch.Tensor) -> torch.Tensor:
+    """In place: every row of a HolE table -> its packed half spectrum (ge_hole_to_spectral).  On the
+    result, model="hole_spectral" scores / trains README.md:42's HolE without any transform."""
+    emb = _table(embeddings)
+    _lib.call("ge_hole_to_spectral", emb.data_ptr(), emb.shape[0], emb.shape[1], _stream())
+    return emb
+
+
+def hole_from_spectral(embeddings: torch.Tensor) -> torch.Tensor:
+    """In place inverse of hole_to_spectral."""
+    emb = _table(embeddings)
+    _lib.call("ge_hole_from_spectral", emb.data_ptr(), emb.shape[0], emb.shape[1], _stream())
+    return emb
 
 
 @dataclass
@@ -189,9 +206,19 @@ class HingeSGD:
         B = p.shape[0]
         self._reserve(B)
         loss = torch.empty(B, dtype=torch.float32, device=emb.device)
-        fn = "ge_complex_hinge_step" if self.model == MODEL_COMPLEX else "ge_hole_hinge_step"
         ws = self._ws[self._turn % self._ws.shape[0]]
         self._turn += 1
+        if self.model == MODEL_HOLE_SPECTRAL:    # the two halves of the step through their own entry points
+            gi = ws[:24 * B].view(torch.int32)
+            off = (24 * B + 255) // 256 * 256
+            gv = ws[off:off + 24 * B * emb.shape[1]].view(torch.float32).view(6 * B, emb.shape[1])
+            _lib.call("ge_hinge_grad", emb.data_ptr(), emb.shape[0], emb.shape[1], p.data_ptr(), n.data_ptr(), B,
+                      self.margin, float(lr), self.max_norm, self.model, loss.data_ptr(), gi.data_ptr(), gv.data_ptr(),
+                      _stream())
+            _lib.call("ge_scatter_add_rows", emb.data_ptr(), emb.shape[0], emb.shape[1], gi.data_ptr(), gv.data_ptr(),
+                      6 * B, _stream())
+            return loss.view(-1, 1)
+        fn = "ge_complex_hinge_step" if self.model == MODEL_COMPLEX else "ge_hole_hinge_step"
         _lib.call(fn, emb.data_ptr(), emb.shape[0], emb.shape[1], p.data_ptr(), n.data_ptr(), B,
                   self.margin, float(lr), self.max_norm, loss.data_ptr(), ws.data_ptr(),
                   ws.numel(), _stream())
@@ -320,7 +347,7 @@ class Trainer:
                  batch_size: int, *, margin: float = 0.2, learning_rate: float = 0.1,
                  decay_steps: float = 0.0, decay_rate: float = 0.5, model="complex", max_norm: float = 1.0,
                  seed: int = 0, corrupt_mode: int = CORRUPT_BATCH_COIN, prepared: bool = True,
-                 lookahead: bool = True):
+                 lookahead: bool = True, spectral_resident: bool = False):
         self.embeddings = _table(embeddings)
         self.triples = _triples(triples, "triples")
         if self.triples.shape[0] < batch_size:
@@ -333,6 +360,15 @@ class Trainer:
         self.global_step = 0
         self.row = 0
         dev = self.embeddings.device
+        # model="hole" hands ge_train_steps the real-valued table: every run() transforms it to the frequency
+        # domain and back (two O(N d^2) passes per call).  spectral_resident=True transforms ONCE, here, keeps
+        # `embeddings` spectral between calls (score it with model="hole_spectral") and to_real() undoes it.
+        self.spectral = False
+        if spectral_resident:
+            if self.model != MODEL_HOLE or (self.embeddings.shape[1] & 1):
+                raise ValueError("spectral_resident needs model='hole' and an even embedding_dim")
+            hole_to_spectral(self.embeddings)
+            self.model, self.spectral = MODEL_HOLE_SPECTRAL, True
         # prepared=False: only the single-step workspace -> ge_train_steps takes its fallback branch
         # (per-step sampler launch + float-atomic scatter); lookahead=False: no pipeline handle, the
         # prepare launches go to the caller's stream and nothing survives between run() calls
@@ -362,6 +398,16 @@ class Trainer:
             self.close()
         except Exception:
             pass
+
+    def to_real(self):
+        """Leave the resident-spectral mode: `embeddings` becomes the real-valued HolE table again."""
+        if self.spectral:
+            hole_from_spectral(self.embeddings)
+            self.model, self.spectral = MODEL_HOLE, False
+
+    def real_embeddings(self) -> torch.Tensor:
+        """A real-valued copy of the table (checkpoints, evaluation), whatever domain it is held in."""
+        return hole_from_spectral(self.embeddings.clone()) if self.spectral else self.embeddings
 
     def invalidate(self):
         """Forget the records prepared ahead (call after changing `triples` or the type tables in place)."""

@@ -101,7 +101,11 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
     trainer = H.Trainer(embeddings, triples, tt, FLAGS.batch_size, margin=FLAGS.margin,
                         learning_rate=FLAGS.learning_rate,
                         decay_steps=FLAGS.learning_decay_steps * batch_count,
-                        decay_rate=FLAGS.learning_decay_rate, model=FLAGS.model, seed=FLAGS.seed)
+                        decay_rate=FLAGS.learning_decay_rate, model=FLAGS.model, seed=FLAGS.seed,
+                        spectral_resident=(FLAGS.model == 'hole' and FLAGS.embedding_dim % 2 == 0 and not FLAGS.log_loss))
+    # HolE: `embeddings` is held in the frequency domain while training (hole.Trainer); validation scores it
+    # there (model 'hole_spectral'), checkpoints store the real-valued table
+    eval_model = 'hole_spectral' if trainer.spectral else FLAGS.model
     trainer.global_step = global_step
     gen = torch.Generator(device='cuda').manual_seed(FLAGS.seed)
     valid = None
@@ -145,13 +149,13 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
                     vlm = float(logloss_steps(1, lr_zero=True, batch_override=valid[sel].contiguous()).mean())
                 else:
                     vlm = float(H.evaluate_batch(valid[sel], embeddings, tt, None, data.relation_count,
-                                                 margin=FLAGS.margin, model=FLAGS.model, seed=FLAGS.seed ^ 0x5EED,
+                                                 margin=FLAGS.margin, model=eval_model, seed=FLAGS.seed ^ 0x5EED,
                                                  step=trainer.global_step).mean())
                 log('\tStep {} Validation Loss: {}...'.format(trainer.global_step, vlm))
                 history.append((trainer.global_step, vlm))
                 if vlm < pocket_loss:
                     pocket_loss = vlm
-                    save_checkpoint(FLAGS.output_dir, embeddings, trainer.global_step)
+                    save_checkpoint(FLAGS.output_dir, trainer.real_embeddings(), trainer.global_step)
                     log('Epoch {}, (Model saved with loss {})'.format(epoch, vlm))
             # steps up to the next validation tick (or the end of the epoch), enqueued natively
             nxt = min(batch_count, (batch // tick + 1) * tick)
@@ -172,6 +176,7 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
             break
     torch.cuda.synchronize()
     log('Done training -- epoch limit reached')
+    trainer.to_real()
     if not os.path.exists(checkpoint_path(FLAGS.output_dir)):
         save_checkpoint(FLAGS.output_dir, embeddings, trainer.global_step)
     steps = trainer.global_step - global_step

@@ -40,6 +40,12 @@ extern "C" {
 #define GE_CORRUPT_HEADS 2      /* holE.py:97-114 */
 #define GE_CORRUPT_TAILS 3      /* holE.py:117-133 */
 
+/* model codes (ge_hinge_loss, ge_hinge_grad, ge_train_steps) */
+#define GE_MODEL_COMPLEX 0       /* holE.py:191-192 */
+#define GE_MODEL_HOLE 1          /* README.md:42 on a real-valued table */
+#define GE_MODEL_HOLE_SPECTRAL 2 /* the same model on a table transformed by ge_hole_to_spectral */
+#define GE_MODEL_HOLE_DIRECT 3   /* ge_train_steps only: force the direct-correlation kernels */
+
 int ge_version(void);
 
 /* Largest embedding_dim the compiled kernels accept (score path / train path). */
@@ -56,8 +62,21 @@ int ge_complex_score(const float* table, int64_t N, int32_t d, const int32_t* tr
 int ge_hole_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
                   float max_norm, int apply_sigmoid, float* out, void* stream);
 
+/* --- HolE in the frequency domain.  ge_hole_to_spectral replaces every row x (d reals, d even, k = d/2)
+ * IN PLACE by its half spectrum X_f = sum_n x_n exp(-2 pi i f n / d), packed into the same d floats as
+ * [Re X_0 .. Re X_{k-1} | Re X_k, Im X_1 .. Im X_{k-1}] (X_0 and the Nyquist bin X_k are real);
+ * ge_hole_from_spectral is the inverse.  On a spectral table the HolE score of README.md:42 is
+ * (1/d) sum_f w_f Re(H_f R_f conj(T_f)), w_0 = w_k = 1, else 2 -- the ComplEx-shaped trilinear form --
+ * and |x|^2 = (1/d) sum_f w_f |X_f|^2, so scoring, the max-norm clip and the SGD step run without any
+ * transform (model GE_MODEL_HOLE_SPECTRAL).  ge_hole_spectral_score = ge_hole_score on such a table. */
+int ge_hole_to_spectral(float* table, int64_t N, int32_t d, void* stream);
+int ge_hole_from_spectral(float* table, int64_t N, int32_t d, void* stream);
+int ge_hole_spectral_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
+                           float max_norm, int apply_sigmoid, float* out, void* stream);
+
 /* --- evaluate_batch forward only (holE.py:222-234): loss[i] = max(E(pos_i) - E(neg_i) + margin, 0).
- * model: 0 = ComplEx, 1 = HolE.  sig_out (nullable) receives E(pos) in [0,B) and E(neg) in [B,2B). */
+ * model: GE_MODEL_COMPLEX, GE_MODEL_HOLE or GE_MODEL_HOLE_SPECTRAL.  sig_out (nullable) receives E(pos) in
+ * [0,B) and E(neg) in [B,2B). */
 int ge_hinge_loss(const float* table, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
                   int64_t B, float margin, float max_norm, int model, float* loss, float* sig_out,
                   void* stream);
@@ -93,7 +112,8 @@ int ge_complex_logloss_step(float* table, int64_t N, int32_t d, const int32_t* t
  * ge_hinge_grad: `rows` is any [N,d] row store (the table itself, or a staging buffer of fetched
  * rows with pos/neg re-indexed into it).  Emits IndexedSlices: grad_idx [6B] int32 (row index in
  * `rows`, or -1 for an empty slot) and grad_val [6B,d] fp32 already multiplied by -lr, slot order
- * per pair: h+, t+, r+, h-, t-, r-.  model: 0 = ComplEx, 1 = HolE.
+ * per pair: h+, t+, r+, h-, t-, r-.  model: GE_MODEL_COMPLEX, GE_MODEL_HOLE or GE_MODEL_HOLE_SPECTRAL
+ * (then `rows` holds spectral rows and the emitted gradient rows are spectral too).
  * ge_scatter_add_rows: table[idx[i]] += val[i] for idx[i] >= 0, float atomics.
  * ge_gather_rows: out[i] = table[idx[i]] (zeros for idx[i] < 0). */
 int ge_hinge_grad(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
@@ -187,7 +207,11 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * to `stream` itself and the library keeps no state whatsoever.
  *
  * neg_ws: device [B,3] int32 scratch (holds the last step's negatives on return).  loss: device
- * [n_steps*B] when keep_all_losses, else [B] (last step).  model: 0 ComplEx, 1 HolE.
+ * [n_steps*B] when keep_all_losses, else [B] (last step).  model: GE_MODEL_COMPLEX; GE_MODEL_HOLE (real
+ * table; for even d the call transforms it to the frequency domain on entry, runs the spectral steps
+ * and transforms back on exit -- two O(N d^2) passes per call, so prefer long calls or keep the table
+ * spectral); GE_MODEL_HOLE_SPECTRAL (table already spectral, no transforms); GE_MODEL_HOLE_DIRECT
+ * (direct-correlation kernels on the real table, O(d^2) per triple).
  * ev_pairs (nullable, HOST array of 2*n_steps events from ge_event_create): the events ride on the
  * dispatch of kernel `ev_kernel` of every step (1 = gather+score+hinge+grad, 2 = row update; 0 =
  * the per-step sampler of the fallback path) and report that kernel's own begin/end -- the hook

@@ -186,6 +186,7 @@ def test_all_inactive_margin_leaves_table_bit_identical(H, G):
 
 # ---------------------------------------------------------------- config-2 size against the C port
 @pytest.mark.parametrize("model,d,B", [("complex", 200, 4096), ("complex", 50, 128), ("hole", 200, 1024),
+                                       ("hole", 200, 4096),      # BASELINE config 3 at its headline batch
                                        # HolE beyond one 256-lag chunk: 16-byte path (300) and the generic path (258, 67)
                                        ("hole", 300, 96), ("hole", 258, 64), ("hole", 67, 64), ("hole", 512, 32),
                                        ("complex", 1024, 64), ("complex", 6, 64)])
@@ -420,7 +421,9 @@ def test_sharded_trainer_single_rank_uses_hip_kernels(H):
 
 # ---------------------------------------------------------------- native training loop (ge_train_steps)
 @pytest.mark.parametrize("model,B,d,steps", [("complex", 1024, 200, 70), ("complex", 4096, 200, 6),
-                                             ("complex", 100, 50, 9), ("hole", 256, 64, 5)])
+                                             ("complex", 100, 50, 9), ("hole", 256, 64, 5), ("hole_direct", 256, 64, 5),
+                                             ("hole", 128, 67, 4),          # odd d: no packed half spectrum, direct kernels
+                                             ("hole", 4096, 200, 12)])      # BASELINE config 3 shape (spectral steps)
 def test_train_steps_match_c_port_step_by_step(H, model, B, d, steps):
     """ge_train_steps (prepared path: bulk negatives + LDS-sorted slot index + one RMW per distinct
     row) against the C port replaying the same loop: same batches (incl. the wrap that never yields a
@@ -449,7 +452,7 @@ def test_train_steps_match_c_port_step_by_step(H, model, B, d, steps):
         gs = 3 + s
         neg = CO.corrupt_batch(pos, id_to_type, offsets, ids, 21, gs, 1024, 0)
         lr = np.float32(0.1) / (np.float32(1.0) + np.float32(0.5) * (np.float32(gs) / np.float32(50.0)))
-        closs = CO.hinge_step(ctab, pos, neg, 0.2, float(lr), hole=(model == "hole"), threads=8)
+        closs = CO.hinge_step(ctab, pos, neg, 0.2, float(lr), hole=model.startswith("hole"), threads=16)
         assert np.abs(losses[s] - closs).max() < 2e-5, s
         row += B
     assert tr.row == row
@@ -527,6 +530,113 @@ def test_bernoulli_sampler_bit_exact_vs_pinned_oracle(H):
     known = {tuple(x) for x in tri}
     ok = neg[:, 2] >= 0
     assert not any(tuple(int(v) for v in row) in known for row in neg[ok])
+
+
+# ---------------------------------------------------------------- HolE in the frequency domain
+def _packed_rfft(x):
+    """NumPy statement of the packed half spectrum of ge_hole_to_spectral."""
+    X = np.fft.rfft(x.astype(np.float64), axis=1)
+    k = x.shape[1] // 2
+    out = np.empty_like(x, dtype=np.float64)
+    out[:, :k] = X[:, :k].real
+    out[:, k] = X[:, k].real
+    out[:, k + 1:] = X[:, 1:k].imag
+    return out
+
+
+@pytest.mark.parametrize("d", [200, 64, 50, 2, 1024])
+def test_hole_spectral_transform_round_trip(H, d):
+    rng = np.random.default_rng(d)
+    N = 777
+    x = (rng.standard_normal((N, d)) * rng.uniform(0.01, 0.3, (N, 1))).astype(np.float32)
+    x[3] = 0.0
+    t = dev(x).clone()
+    H.hole_to_spectral(t)
+    ref = _packed_rfft(x)
+    assert np.abs(t.cpu().numpy() - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    # Parseval with Hermitian weights: the clip norm is available without transforming back
+    w = np.full(d, 2.0); w[0] = 1.0; w[d // 2] = 1.0
+    assert np.abs((ref ** 2 * w).sum(1) / d - (x.astype(np.float64) ** 2).sum(1)).max() < 1e-9
+    H.hole_from_spectral(t)
+    assert np.abs(t.cpu().numpy() - x).max() < 2e-6 * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize("d", [200, 50, 128])
+def test_hole_spectral_scores_and_step_match_the_hole_oracle(H, G, d):
+    """README.md:42's HolE evaluated on the spectral table (ComplEx-shaped kernels with Hermitian weights):
+    sigma(score), hinge and one SGD step equal the fp64 numpy.fft oracle on the real table."""
+    table, pos, neg = G[f"d{d}_table"], G[f"d{d}_pos"], G[f"d{d}_neg"]
+    t64 = table.astype(np.float64)
+    spec = H.hole_to_spectral(dev(table).clone())
+    sig = H.evaluate_triples(dev(pos), spec, model="hole_spectral").cpu().numpy()[:, 0]
+    assert np.abs(sig - O.hole_evaluate_triples(pos, t64)[:, 0]).max() < SCORE_TOL
+    for margin in (0.2, 0.0):
+        loss = H.hinge_loss(dev(pos), dev(neg), spec, margin=margin, model="hole_spectral").cpu().numpy()[:, 0]
+        assert np.abs(loss - O.evaluate_batch(pos, neg, t64, margin=margin, model="hole")[:, 0]).max() < SCORE_TOL
+    work = spec.clone()
+    loss = H.HingeSGD(work, len(pos), margin=0.2, model="hole_spectral").step(dev(pos), dev(neg), 0.1).cpu().numpy()[:, 0]
+    new, oloss = O.sgd_step(t64, pos, neg, lr=0.1, margin=0.2, model="hole")
+    assert np.abs(loss - oloss).max() < SCORE_TOL
+    assert np.abs(H.hole_from_spectral(work).cpu().numpy() - new).max() < TABLE_TOL
+
+
+def test_hole_config3_fifty_dependent_spectral_steps_vs_fp64_oracle(H):
+    """BASELINE config 3 (FB15k-shaped, HolE d=200, B=4096) through ge_train_steps: the table is carried
+    in the frequency domain for 50 dependent steps, then transformed back.  Against the fp64 numpy.fft
+    oracle replaying the same loop (same Philox negatives, fp32 LR schedule): every step's loss vector
+    within 1e-5, the final table within 2e-5."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    B, d, steps = 4096, 200, 50
+    T = 7 * B + 13
+    tri = D.synthetic_fb15k_triples(fb, n_triples=T, seed=17)
+    table = O.init_table(fb.entity_count, d, seed=8)
+    table[::4] *= 7.0                                # rows outside the unit ball
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    emb = dev(table).clone()
+    tr = H.Trainer(emb, dev(tri), tt, B, margin=0.2, learning_rate=0.1, decay_steps=200.0, decay_rate=0.5,
+                   model="hole", seed=33)
+    losses = tr.run(steps, keep_losses=True).cpu().numpy()
+    t64 = table.astype(np.float64)
+    row, worst = 0, 0.0
+    for s in range(steps):
+        if row + B > T:
+            row = 0
+        pos = tri[row:row + B]
+        neg = CO.corrupt_batch(pos, id_to_type, offsets, ids, 33, s, 1024, 0)
+        lr = np.float32(0.1) / (np.float32(1.0) + np.float32(0.5) * (np.float32(s) / np.float32(200.0)))
+        t64, oloss = O.sgd_step(t64, pos, neg, lr=float(lr), margin=0.2, model="hole")
+        worst = max(worst, float(np.abs(losses[s] - oloss).max()))
+        row += B
+    assert worst < 1e-5, worst
+    assert np.abs(emb.cpu().numpy() - t64).max() < 2e-5
+    tr.close()
+
+
+def test_hole_resident_spectral_trainer_equals_per_call_transform(H):
+    """Trainer(spectral_resident=True) transforms once and keeps the table spectral across run() calls;
+    the default transforms in and out on every call.  Same losses, same final real table."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    tri = dev(D.synthetic_fb15k_triples(fb, n_triples=40000, seed=3))
+    base = H.init_embeddings(fb.entity_count, 200, seed=5) * 5.0
+    outs, losses = [], []
+    for resident in (False, True):
+        emb = base.clone()
+        tr = H.Trainer(emb, tri, tt, 2048, model="hole", seed=6, spectral_resident=resident)
+        ls = torch.stack([tr.run(7).clone() for _ in range(4)])
+        if resident:
+            v = H.evaluate_triples(tri[:100], emb, model="hole_spectral")
+            assert (v - H.evaluate_triples(tri[:100], tr.real_embeddings(), model="hole")).abs().max().item() < SCORE_TOL
+            tr.to_real()
+        torch.cuda.synchronize()
+        outs.append(emb); losses.append(ls)
+        tr.close()
+    assert (losses[0] - losses[1]).abs().max().item() < 2e-6
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-6
 
 
 # ---------------------------------------------------------------- the prepare launch on its own
