@@ -382,41 +382,64 @@ def test_score_candidates_matches_per_triple_scores(H, d, B, K, cand_is_head):
 
 
 def test_score_candidates_full_fb15k_shape(H):
-    # config 5 shape: B=4096 positives x 256 shared negatives, d=200
+    # BASELINE config 5 at full size: B=4096 positives x 256 shared negatives, d=200, through the fp32-MFMA GEMM;
+    # 2,000 sampled cells against the fp64 ORACLE (not against another kernel of this library)
     N, d, B, K = 16296, 200, 4096, 256
     g = torch.Generator(device="cpu").manual_seed(1)
-    table = (torch.randn(N, d, generator=g) * 0.12).cuda()
-    hr = torch.stack([torch.randint(1345, N, (B,), generator=g), torch.randint(0, 1345, (B,), generator=g)], 1).int().cuda()
-    cand = torch.randint(1345, N, (K,), generator=g).int().cuda()
-    out = H.score_candidates(table, hr, cand)
+    table = (torch.randn(N, d, generator=g) * 0.12)
+    table[::6] *= 3.0                                                   # rows outside the unit ball
+    hr = torch.stack([torch.randint(1345, N, (B,), generator=g), torch.randint(0, 1345, (B,), generator=g)], 1).int()
+    cand = torch.randint(1345, N, (K,), generator=g).int()
+    t64 = table.numpy().astype(np.float64)
     rows = torch.randint(0, B, (2000,), generator=g)
     cols = torch.randint(0, K, (2000,), generator=g)
-    tr = torch.stack([hr[rows.cuda(), 0], cand[cols.cuda()], hr[rows.cuda(), 1]], 1).contiguous()
-    per = H.evaluate_triples(tr, table)[:, 0]
-    assert (out[rows.cuda(), cols.cuda()] - per).abs().max().item() < SCORE_TOL
+    for cand_is_head in (False, True):
+        out = H.score_candidates(table.cuda(), hr.cuda(), cand.cuda(), cand_is_head=cand_is_head).cpu()
+        fixed, c, rel = hr[rows, 0].numpy(), cand[cols].numpy(), hr[rows, 1].numpy()
+        tr = np.stack([c, fixed, rel], 1) if cand_is_head else np.stack([fixed, c, rel], 1)
+        ref = O.evaluate_triples(tr, t64)[:, 0]
+        assert np.abs(out[rows, cols].numpy() - ref).max() < SCORE_TOL
 
 
 # ---------------------------------------------------------------- row-sharded path, HIP kernels
-def test_sharded_trainer_single_rank_uses_hip_kernels(H):
+@pytest.mark.parametrize("shape", ["fb15k", "config4"])
+def test_sharded_trainer_single_rank_uses_hip_kernels(H, shape):
     """world_size 1 on the GPU: the exchange degenerates to local copies, the four kernels are the
-    real HIP ones.  Result must equal the plain fused step (same negatives)."""
+    real HIP ones.  Result must equal the plain fused step (same negatives) and the C port.  config4 =
+    BASELINE config 4's workload: 1,200,018 x 200 table (960 MB), Zipf(0.8) ids, B = 16,384."""
     from graphembeddings_amd import data as D
     from graphembeddings_amd import sharded as S
-    fb = D.fb15k_shape()
-    names, id_to_type, offsets, ids = fb.type_arrays()
+    if shape == "fb15k":
+        fb = D.fb15k_shape()
+        names, id_to_type, offsets, ids = fb.type_arrays()
+        table_h = O.init_table(fb.entity_count, 200, seed=2) * 6.0
+        B = 2048
+        pos_h = D.synthetic_fb15k_triples(fb, n_triples=B, seed=3)
+        n_rows, n_rel = fb.entity_count, fb.relation_count
+    else:
+        B = 16384
+        data, pos_h = D.synthetic_large(n_entities=1_200_000, n_triples=B, seed=1234)
+        names, id_to_type, offsets, ids = D.synthetic_large_type_arrays(data)
+        table_h = np.random.default_rng(5).standard_normal((data.entity_count, 200), dtype=np.float32) * np.float32(0.02)
+        table_h[::7] *= np.float32(5.0)
+        n_rows, n_rel = data.entity_count, data.relation_count
     tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
-    table = dev(O.init_table(fb.entity_count, 200, seed=2) * 6.0)
-    pos = dev(D.synthetic_fb15k_triples(fb, n_triples=2048, seed=3))
+    table = dev(table_h)
+    pos = dev(pos_h)
     a = table.clone()
-    tr = S.ShardedTrainer(a, fb.entity_count, tt, seed=4)
+    tr = S.ShardedTrainer(a, n_rows, tt, seed=4)
     loss_s = tr.step(pos, lr=0.1)
-    neg = H.corrupt_batch(tt, fb.relation_count, pos, seed=4, step=0)
+    neg = H.corrupt_batch(tt, n_rel, pos, seed=4, step=0)
     b = table.clone()
-    loss_p = H.HingeSGD(b, 2048).step(pos, neg, 0.1)[:, 0]
+    loss_p = H.HingeSGD(b, B).step(pos, neg, 0.1)[:, 0]
     torch.cuda.synchronize()
     assert (loss_s - loss_p).abs().max().item() < SCORE_TOL
     assert (a - b).abs().max().item() < TABLE_TOL
     assert tr.stats.unique_rows > 0 and tr.stats.remote_rows == 0
+    ctab = table_h.copy()
+    closs = CO.hinge_step(ctab, pos_h, neg.cpu().numpy(), 0.2, 0.1, threads=16)
+    assert np.abs(loss_s.cpu().numpy() - closs).max() < SCORE_TOL
+    assert np.abs(a.cpu().numpy() - ctab).max() < 2e-5
 
 
 # ---------------------------------------------------------------- native training loop (ge_train_steps)
