@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="skip the 1-GPU run of the row-sharded config[3] workload that the N>1 lines are comparable to")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--partition", default="head", choices=["head", "random"],
+                    help="N>1: which triples a rank trains -- those whose head row it owns (default), or a random share")
+    ap.add_argument("--plan-group", action="store_true",
+                    help="N>1: run the exchange planner's collectives on a second communicator (untested on hardware)")
     ap.add_argument("--entities", type=int, default=1_200_000)
     ap.add_argument("--triples", type=int, default=30_000_000)
     return ap.parse_args()

@@ -23,7 +23,10 @@ namespace ge {
 template <bool SPEC, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_score_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ triples, int64_t B,
-    float max_norm, int apply_sigmoid, float* __restrict__ out) {
+    float max_norm, int apply_sigmoid, float* __restrict__ out, float label, float l2,
+    const float* __restrict__ table_sumsq) {
+  // apply_sigmoid: 0 raw score, 1 sigmoid (holE.py:198), 2 the --log_loss branch of evaluate_triples
+  // (holE.py:194-196): log(1 + exp(-label * score)) + l2 * l2_loss(whole table)
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -42,7 +45,14 @@ __global__ __launch_bounds__(kBlock) void complex_score_kernel(
     load_row<VEC, LPT, NITER>(table, ti, d, k, nvec, sub, t);
     load_row<VEC, LPT, NITER>(table, ri, d, k, nvec, sub, r);
     const SideFwd f = side_forward<SPEC, VEC, LPT, NITER>(h, t, r, max_norm, sub == 0, wscale);
-    if (live && sub == 0) out[g] = bad ? __builtin_nanf("") : (apply_sigmoid ? f.sig : f.s);
+    if (live && sub == 0) {
+      float v = apply_sigmoid == 1 ? f.sig : f.s;
+      if (apply_sigmoid == 2) {
+        const float z = -label * f.s;
+        v = (z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z))) + l2 * 0.5f * table_sumsq[0];
+      }
+      out[g] = bad ? __builtin_nanf("") : v;
+    }
   }
 }
 
@@ -315,14 +325,15 @@ static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
   } while (0)
 
 int complex_score_launch(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
-                         float max_norm, int apply_sigmoid, float* out, hipStream_t st, int spectral) {
+                         float max_norm, int apply_sigmoid, float* out, hipStream_t st, int spectral, float label,
+                         float l2, const float* table_sumsq) {
   Shape s;
   if (!pick_shape(d, table, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   if (B == 0) return 0;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipLaunchKernelGGL((complex_score_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out)
+  hipLaunchKernelGGL((complex_score_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out, label, l2, table_sumsq)
   GE_DISPATCH_SPEC(spectral, s, CALL);
 #undef CALL
   return launch_status();

@@ -11,7 +11,6 @@ ge_complex_score_1vK (fp32-MFMA GEMM), for tails and -- as FB15k protocols need 
 from __future__ import annotations
 
 from collections import defaultdict
-from heapq import heappop, heappush
 
 import numpy as np
 import torch
@@ -19,50 +18,15 @@ import torch
 from . import hole as H
 
 
-def eval_link_prediction(scores, id_to_metadata, true_triples, test_triples, max_triples,
-                         raw_positions, filtered_positions, infer_threshold=None, output=None):
-    """Host version with the reference's signature (holE.py:427-428) for one candidate list:
-    `scores` iterates (loss_row, triple) pairs as `zip(batch_loss, triples)` does (holE.py:571).
-    Printing is dropped; `output` (file-like, optional) receives the inference_results.tsv lines
-    (holE.py:456).  infer_threshold=None disables the is_confident gate (holE.py:438)."""
-    heap = []
-    min_loss = 100
-    for pair in scores:
-        loss = float(np.asarray(pair[0]).reshape(-1)[0])
-        min_loss = min(min_loss, loss)
-        heappush(heap, (loss, tuple(int(v) for v in pair[1])))
-    is_confident = True if infer_threshold is None else (min_loss < infer_threshold)
-    raw_rank = 0
-    filtered_rank = 0
-    while heap:
-        loss, (head_id, tail_id, relation_id) = heappop(heap)
-        raw_rank += 1
-        in_sample = tail_id in true_triples[head_id][relation_id]
-        if output is not None and is_confident and filtered_rank < max_triples:
-            output.write('{:.6f}\t{}\t{}\t{}\t{}\n'.format(loss, head_id, tail_id, relation_id, in_sample))
-        if is_confident and in_sample:
-            continue
-        filtered_rank += 1
-        if is_confident and tail_id in test_triples[head_id][relation_id]:
-            raw_positions.append(raw_rank)
-            filtered_positions.append(filtered_rank)
-
-
-def score_mrr(raw_positions, filtered_positions, verbose: bool = True) -> dict:
-    """holE.py:475-490: raw / filtered MRR, mean positions, Hits@1/3/10 (percent)."""
-    raw = np.array(raw_positions, dtype=np.float64)
-    fil = np.array(filtered_positions, dtype=np.float64)
-    out = {
-        "raw_mrr": float(np.mean(1.0 / raw)), "mean_raw_pos": float(np.mean(raw)),
-        "filtered_mrr": float(np.mean(1.0 / fil)), "mean_filtered_pos": float(np.mean(fil)),
-        "hits1": float(np.mean(fil <= 1).sum() * 100), "hits3": float(np.mean(fil <= 3).sum() * 100),
-        "hits10": float(np.mean(fil <= 10).sum() * 100),
-    }
-    if verbose:
-        print('Raw MRR: {} (mean position: {})'.format(out["raw_mrr"], out["mean_raw_pos"]))
-        print('Filtered MRR: {} (mean position: {})'.format(out["filtered_mrr"], out["mean_filtered_pos"]))
-        print('Hits at 1: {}, 3: {}, 10: {}'.format(out["hits1"], out["hits3"], out["hits10"]))
-    return out
+def mrr_and_hits(raw_ranks, filtered_ranks) -> dict:
+    """The summary numbers of holE.py:475-490 from rank arrays: reciprocal-rank means, mean ranks and the
+    share of filtered ranks within 1 / 3 / 10 (percent)."""
+    raw = np.asarray(raw_ranks, dtype=np.float64)
+    fil = np.asarray(filtered_ranks, dtype=np.float64)
+    pct = lambda n: 100.0 * float(np.count_nonzero(fil <= n)) / max(1, fil.size)
+    return {"raw_mrr": float((1.0 / raw).mean()), "mean_raw_pos": float(raw.mean()),
+            "filtered_mrr": float((1.0 / fil).mean()), "mean_filtered_pos": float(fil.mean()),
+            "hits1": pct(1), "hits3": pct(3), "hits10": pct(10)}
 
 
 def _known_lists(known_triples: np.ndarray, side: str):
@@ -143,4 +107,8 @@ def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True
     if both_sides:
         raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known, "head", batch)
         raw.append(raw_h); fil.append(fil_h)
-    return score_mrr(np.concatenate(raw), np.concatenate(fil), verbose=verbose)
+    out = mrr_and_hits(np.concatenate(raw), np.concatenate(fil))
+    if verbose:
+        print("raw MRR {raw_mrr:.6f} (mean rank {mean_raw_pos:.1f}); filtered MRR {filtered_mrr:.6f} "
+              "(mean rank {mean_filtered_pos:.1f}); hits@1/3/10 {hits1:.2f} / {hits3:.2f} / {hits10:.2f} %".format(**out))
+    return out

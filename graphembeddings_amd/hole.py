@@ -53,28 +53,35 @@ def _triples(t: torch.Tensor, name="triple_batch") -> torch.Tensor:
 
 def init_embeddings(entity_count: int, embedding_dim: int, device="cuda", seed: Optional[int] = None):
     """The `embeddings` variable of holE.py:263-264: xavier_initializer(uniform=False) =
-    truncated normal (re-drawn beyond 2 sigma) with stddev sqrt(2.6 / (entity_count + dim))."""
-    gen = torch.Generator(device="cpu")
+    truncated normal (re-drawn beyond 2 sigma) with stddev sqrt(2.6 / (entity_count + dim)), drawn on the
+    device (a 960 MB table is not built on the host and copied)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
     if seed is not None:
         gen.manual_seed(seed)
     std = float(np.sqrt(2.6 / (entity_count + embedding_dim)))
-    t = torch.empty(entity_count, embedding_dim, dtype=torch.float32)
+    t = torch.empty(entity_count, embedding_dim, dtype=torch.float32, device=dev)
     torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
-    return t.to(device)
+    return t
 
 
 def evaluate_triples(triple_batch: torch.Tensor, embeddings: torch.Tensor, label=None, *,
-                     model="complex", max_norm: float = 1.0, apply_sigmoid: bool = True) -> torch.Tensor:
-    """holE.py:179-202 (hinge / inference branch): sigmoid(sum_k Re(h_k r_k conj(t_k))) as [B,1].
-
-    `label` is accepted for signature compatibility; the log-loss branch (holE.py:194-196) is out of
-    scope and raises.  model="hole" gives the README.md:42 HolE score instead.
-    """
-    if label is not None:
-        raise NotImplementedError("log_loss mode (holE.py:194-196) is not part of this path")
+                     model="complex", max_norm: float = 1.0, apply_sigmoid: bool = True,
+                     l2_regularization: float = 0.1) -> torch.Tensor:
+    """holE.py:179-202 as [B,1].  label=None (hinge / inference branch): sigmoid(sum_k Re(h_k r_k conj(t_k))).
+    label=+1 / -1 (the --log_loss branch, holE.py:194-196; FLAGS.l2_regularization becomes a keyword):
+    log(1 + exp(-label * score)) + l2_regularization * l2_loss(embeddings), ComplEx score only.
+    model="hole" gives the README.md:42 HolE score instead ("hole_spectral": on a spectral table)."""
     emb = _table(embeddings)
     tb = _triples(triple_batch)
     out = torch.empty(tb.shape[0], dtype=torch.float32, device=emb.device)
+    if label is not None:
+        if _MODELS[model] != MODEL_COMPLEX:
+            raise NotImplementedError("the log-loss branch is defined for the ComplEx score (holE.py:191-196)")
+        ws = torch.empty(256, dtype=torch.uint8, device=emb.device)
+        _lib.call("ge_complex_logloss", emb.data_ptr(), emb.shape[0], emb.shape[1], tb.data_ptr(), tb.shape[0],
+                  float(label), float(l2_regularization), max_norm, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+        return out.view(-1, 1)
     fn = {MODEL_COMPLEX: "ge_complex_score", MODEL_HOLE: "ge_hole_score", MODEL_HOLE_DIRECT: "ge_hole_score",
           MODEL_HOLE_SPECTRAL: "ge_hole_spectral_score"}[_MODELS[model]]
     _lib.call(fn, emb.data_ptr(), emb.shape[0], emb.shape[1], tb.data_ptr(), tb.shape[0],

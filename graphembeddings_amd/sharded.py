@@ -141,6 +141,7 @@ class ChunkPlan:
     req_start: list
     reduce_items: SegmentItems = None   # gradient slots -> staged rows (pre-reduction)
     apply_items: SegmentItems = None    # received gradient sums -> shard rows (owner apply)
+    ready: object = None                # event recorded on the side stream when the plan was built there
     unique_rows: int = 0
     remote_rows: int = 0
 
@@ -154,7 +155,7 @@ class StepStats:
 
 class ShardedTrainer:
     def __init__(self, shard: torch.Tensor, n_rows: int, type_tables, *, margin=0.2, model="complex",
-                 max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None):
+                 max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None, plan_group=None):
         self.shard = shard
         self.N = int(n_rows)
         self.d = int(shard.shape[1])
@@ -168,9 +169,15 @@ class ShardedTrainer:
         assert shard.shape[0] == shard_num_rows(self.N, self.rank, self.world)
         self.global_step = 0
         self.stats = StepStats()
+        # run_pipelined builds the NEXT chunk's negatives and exchange plan while the current chunk's steps
+        # execute: on a side stream, with the plan's two collectives (request counts, id lists) on their own
+        # process group (`plan_group`: its own RCCL communicator, so they do not queue behind the row / gradient
+        # all-to-alls of the data path).  Without one the plan shares `group` and still runs on the side stream.
+        self.plan_group = plan_group if plan_group is not None else group
+        self._side = torch.cuda.Stream(device=shard.device) if shard.is_cuda else None
 
     # -- exchange helpers ---------------------------------------------------------------------
-    def _a2a(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
+    def _a2a(self, send: torch.Tensor, send_counts, recv_counts, group=None) -> torch.Tensor:
         """all_to_all_single with per-peer row counts (rows of `send` are grouped by destination)."""
         tail = tuple(send.shape[1:])
         recv = torch.empty((int(sum(recv_counts)),) + tail, dtype=send.dtype, device=send.device)
@@ -178,7 +185,7 @@ class ShardedTrainer:
             recv.copy_(send)
             return recv
         dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_counts),
-                               input_split_sizes=list(send_counts), group=self.group)
+                               input_split_sizes=list(send_counts), group=group if group is not None else self.group)
         return recv
 
     # -- exchange plans -----------------------------------------------------------------------
@@ -217,7 +224,7 @@ class ShardedTrainer:
         if G > 1:
             send_c = counts.t().contiguous()                            # [G,S]: row p -> peer p
             recv_c = torch.empty_like(send_c)
-            dist.all_to_all_single(recv_c, send_c, group=self.group)
+            dist.all_to_all_single(recv_c, send_c, group=self.plan_group)
             both = torch.stack([counts, recv_c.t()]).cpu()              # the host sync for the split sizes
             sc, rc = both[0], both[1]
         else:
@@ -228,7 +235,7 @@ class ShardedTrainer:
             grouped = torch.empty_like(send_ids)
             grouped[_regroup(U, counts)] = send_ids
             send_ids = grouped
-        recv_ids = self._a2a(send_ids, sc.sum(0).tolist(), rc.sum(0).tolist())
+        recv_ids = self._a2a(send_ids, sc.sum(0).tolist(), rc.sum(0).tolist(), group=self.plan_group)
         n_req = int(recv_ids.numel())
         rc_dev = rc.to(dev)
         if G > 1:                                                       # received (peer, step) -> needed (step, peer)
@@ -292,13 +299,70 @@ class ShardedTrainer:
         self.global_step += 1
         return loss
 
-    def sample_negatives(self, pos: torch.Tensor) -> torch.Tensor:
-        """[S,B,3] negatives for S consecutive steps starting at global_step; the Philox stream is keyed
-        by a counter that is distinct per (global step, rank)."""
+    def sample_negatives(self, pos: torch.Tensor, first_step: int = None) -> torch.Tensor:
+        """[S,B,3] negatives for S consecutive steps starting at first_step (default: global_step); the Philox
+        stream is keyed by a counter that is distinct per (global step, rank)."""
         G = self.world
+        s0 = self.global_step if first_step is None else int(first_step)
         return torch.stack([self.k.corrupt_batch(self.tt, pos[s].contiguous(), self.seed,
-                                                 (self.global_step + s) * G + self.rank, self.mode)
+                                                 (s0 + s) * G + self.rank, self.mode)
                             for s in range(pos.shape[0])], 0)
+
+    def _plan_ahead(self, pos: torch.Tensor, first_step: int, inputs_ready=None) -> "ChunkPlan":
+        """Negatives + exchange plan of a chunk that starts at `first_step`, on the side stream.
+        inputs_ready: event after which `pos` is valid (default: everything enqueued on the current stream so
+        far -- which would put the plan BEHIND steps already enqueued, so run_pipelined passes the event it
+        recorded before enqueuing any step)."""
+        pos = pos.to(torch.int32).contiguous()
+        if self._side is None:
+            plan = self.plan_chunk(pos, self.sample_negatives(pos, first_step).to(torch.int32))
+            plan.ready = None
+            return plan
+        if inputs_ready is None:
+            self._side.wait_stream(torch.cuda.current_stream(pos.device))
+        else:
+            self._side.wait_event(inputs_ready)
+        with torch.cuda.stream(self._side):
+            plan = self.plan_chunk(pos, self.sample_negatives(pos, first_step).to(torch.int32))
+            plan.ready = torch.cuda.Event()
+            plan.ready.record(self._side)
+        return plan
+
+    def _adopt(self, plan: "ChunkPlan") -> None:
+        """Make a plan built on the side stream usable on the current one: wait for it, and tell the caching
+        allocator that its tensors are read here (they are freed while these reads may still be queued)."""
+        if getattr(plan, "ready", None) is None:
+            return
+        cur = torch.cuda.current_stream(plan.remap.device)
+        cur.wait_event(plan.ready)
+        for t in (plan.remap, plan.req_all):
+            t.record_stream(cur)
+        for it in (plan.reduce_items, plan.apply_items):
+            for t in (it.order, it.begin, it.length, it.target, it.split_rows):
+                if t.is_cuda:
+                    t.record_stream(cur)
+
+    def run_pipelined(self, chunks, lr_fn) -> torch.Tensor:
+        """Train the chunks (a sequence of pos [S,B,3] tensors) back to back.  The steps of chunk c are
+        enqueued first (asynchronously); chunk c+1's negatives and exchange plan -- which never depend on the
+        table -- are then built on the side stream while those steps execute, so the host's waits inside the
+        planner (its output sizes are data dependent) fall into time the device spends training.
+        Returns every step's losses [sum S, B]."""
+        chunks = [c.to(torch.int32).contiguous() for c in chunks]
+        ready = None
+        if self._side is not None and chunks:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(chunks[0].device))    # every chunk's positives exist from here on
+        plan = self._plan_ahead(chunks[0], self.global_step, ready) if chunks else None
+        losses = []
+        for c in range(len(chunks)):
+            self._adopt(plan)
+            losses += [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
+            done = plan
+            plan = self._plan_ahead(chunks[c + 1], self.global_step, ready) if c + 1 < len(chunks) else None
+            self.stats = StepStats(unique_rows=done.unique_rows // done.S, remote_rows=done.remote_rows // done.S,
+                                   bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)))
+        return torch.stack(losses, 0) if losses else None
 
     def run(self, pos: torch.Tensor, lr_fn, neg: torch.Tensor = None) -> torch.Tensor:
         """Train S consecutive steps on pos [S,B,3]; lr_fn(global_step) -> lr.  Returns losses [S,B]."""

@@ -43,9 +43,22 @@ def run(args, emit=True):
     data, _ = D.synthetic_large(n_entities=n_ent, n_triples=1, seed=1234)
     names, id_to_type, offsets, ids = D.synthetic_large_type_arrays(data)
     tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024, device=dev)
+    # Triples are partitioned BY THE OWNER OF THEIR HEAD (rank r trains the triples whose head row it
+    # holds): a third of a step's entity rows -- and every head-corrupted negative's type lookups aside --
+    # are then local, and the row all-to-all shrinks accordingly.  Same global distribution (Zipf(0.8)
+    # heads and tails, uniform relations): each rank draws from it and keeps its residue class.
     n_loc = max(args.triples // world, B * 8)
     rng = np.random.default_rng(1234 + 7919 * rank)
-    head = n_rel + D._zipf_sample(rng, n_ent, n_loc, 0.8)
+    if world > 1 and getattr(args, "partition", "head") == "head":
+        parts, have = [], 0
+        while have < n_loc:
+            h = n_rel + D._zipf_sample(rng, n_ent, min(n_loc, 4_000_000) * 2, 0.8)
+            h = h[h % world == rank]
+            parts.append(h)
+            have += len(h)
+        head = np.concatenate(parts)[:n_loc]
+    else:
+        head = n_rel + D._zipf_sample(rng, n_ent, n_loc, 0.8)
     tail = n_rel + D._zipf_sample(rng, n_ent, n_loc, 0.8)
     rel = rng.integers(0, n_rel, size=n_loc)
     dtri = torch.as_tensor(np.stack([head, tail, rel], 1).astype(np.int32)).to(dev)
@@ -58,7 +71,12 @@ def run(args, emit=True):
     shard = torch.empty(rows, d, device=dev)
     torch.nn.init.trunc_normal_(shard, 0.0, std, -2 * std, 2 * std, generator=gen)
 
-    tr = S.ShardedTrainer(shard, N, tt, margin=0.2, model=args.model, seed=0)
+    # The planner's two collectives may get their own communicator (--plan-group) so that they overlap the
+    # data path's all-to-alls.  Default off: two RCCL communicators whose kernels are enqueued from two
+    # streams have no cross-rank launch order, the classic multi-communicator hang, and this path has not
+    # run on a multi-GPU node yet; on ONE communicator every rank enqueues in program order.
+    plan_group = dist.new_group(backend=backend) if (world > 1 and getattr(args, "plan_group", False)) else None
+    tr = S.ShardedTrainer(shard, N, tt, margin=0.2, model=args.model, seed=0, plan_group=plan_group)
     batch_count = args.triples // (B * world)
     decay_steps = 32.0 * batch_count
     ev = H.Events(2)
@@ -73,21 +91,21 @@ def run(args, emit=True):
         return out
     timed_grad.pending = False
 
-    CHUNK = 64   # steps planned per exchange plan (one sort / count exchange / few host syncs per chunk)
+    CHUNK = 16   # steps per exchange plan (one sort / count exchange / few host syncs per chunk; the plan of
+                 # chunk c+1 is built on a side stream while chunk c trains)
 
     def lr_fn(gs):
         return H.inverse_time_decay(0.1, gs, decay_steps, 0.5)
 
     def run_steps(first, n):
-        out = None
+        chunks = []
         i = first
         while i < first + n:
             m = min(CHUNK, first + n - i)
             rows = [((j * B) % (n_loc - B)) for j in range(i, i + m)]
-            pos = torch.stack([dtri[r:r + B] for r in rows], 0)
-            out = tr.run(pos, lr_fn)[-1]
+            chunks.append(torch.stack([dtri[r:r + B] for r in rows], 0))
             i += m
-        return out
+        return tr.run_pipelined(chunks, lr_fn)[-1]
 
     def one_step(i):
         return run_steps(i, 1)
@@ -128,7 +146,8 @@ def run(args, emit=True):
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {n_ent} entities / {args.triples} triples, {args.model} d={d}, "
-                                   f"table row-sharded (id % N) over {world} GPU(s), RCCL all-to-all of ids/rows/gradient sums",
+                                   f"table row-sharded (id % N) over {world} GPU(s), triples partitioned by head owner, "
+                                   f"RCCL all-to-all of ids/rows/gradient sums",
                        "batch_per_gpu": B, "embedding_dim": d, "table_rows": N,
                        "table_mb_per_gpu": round(rows * d * 4 / 1e6, 1), "parallelism": f"row-shard x{world}",
                        "per_gpu_value": 2.0 * B * K / el, "unique_rows_per_step": stats.unique_rows,

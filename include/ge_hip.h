@@ -57,6 +57,12 @@ int ge_max_dim(void);
 int ge_complex_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
                      float max_norm, int apply_sigmoid, float* out, void* stream);
 
+/* --- evaluate_triples(triple_batch, embeddings, label) in --log_loss mode (holE.py:194-196), forward only:
+ * out[i] = log(1 + exp(-label * score_i)) + l2 * sum(table^2) / 2 (tf.nn.l2_loss of the WHOLE table).
+ * workspace: >= 256 bytes of device scratch (the table's sum of squares). */
+int ge_complex_logloss(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B, float label,
+                       float l2, float max_norm, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* --- HolE score of README.md:42: sigma(sum_k r_k [h (star) t]_k), circular correlation over the
  * full d real values of the clipped rows.  Same layout as ge_complex_score. */
 int ge_hole_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,

@@ -808,3 +808,34 @@ def test_logloss_step_matches_oracle(H, G, d, K):
     opt.step(dev(pos), dev(negs), 0.0)
     torch.cuda.synchronize()
     assert torch.equal(emb, before)
+
+
+def test_evaluate_triples_with_label_is_the_logloss_branch(H, G):
+    """evaluate_triples(triple_batch, embeddings, label) (holE.py:179, 194-196): label = +1 / -1 returns
+    log(1 + exp(-label * score)) + l2 * l2_loss(embeddings); label = None the sigmoid."""
+    table, pos = G["d200_table"], G["d200_pos"]
+    emb = dev(table)
+    for label in (1, -1):
+        got = H.evaluate_triples(dev(pos), emb, label, l2_regularization=0.003).cpu().numpy()[:, 0]
+        exp = O.logloss_values(pos, np.full(len(pos), float(label)), table.astype(np.float64), 0.003)
+        assert np.abs(got - exp).max() < 2e-5 * max(1.0, np.abs(exp).max())
+    with pytest.raises(NotImplementedError):
+        H.evaluate_triples(dev(pos), emb, 1, model="hole")
+
+
+def test_init_embeddings_is_the_reference_initializer(H):
+    """holE.py:263-264: xavier_initializer(uniform=False) = truncated normal, sigma = sqrt(2.6 / (rows + dim)),
+    re-drawn beyond 2 sigma; drawn on the device.  The two stddev constants are the ones the reference's
+    graph dumps hold."""
+    for (n, d, sigma_ref) in ((35910, 64, 0.00850143656135), (1134637, 128, 0.00151367869694)):
+        assert abs(np.sqrt(2.6 / (n + d)) - sigma_ref) < 1e-9          # the dumps print the fp32 constant
+    n, d = 35910, 64
+    sigma = np.sqrt(2.6 / (n + d))
+    t = H.init_embeddings(n, d, seed=5)
+    assert t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (n, d)
+    assert t.abs().max().item() <= 2 * sigma * (1 + 1e-6)                  # truncation at 2 sigma
+    assert abs(t.mean().item()) < 5e-5
+    # std of a normal truncated at +-2 sigma: sigma * sqrt(1 - 4 phi(2) / (2 Phi(2) - 1)) = 0.87963 sigma
+    assert abs(t.std().item() / sigma - 0.87963) < 3e-3
+    assert (t.abs() > 1.9 * sigma).float().mean().item() > 1e-3             # the tail up to the cut is populated
+    assert torch.equal(t, H.init_embeddings(n, d, seed=5)) and not torch.equal(t, H.init_embeddings(n, d, seed=6))

@@ -59,12 +59,14 @@ def _worker(rank, world, port, q, name):
             shard = torch.as_tensor(np.ascontiguousarray(table[rank::world])).cuda()
             n_rows = table.shape[0]
             del table
-            tr = S.ShardedTrainer(shard, n_rows, tt, margin=0.2, seed=13)
+            # the planner's collectives on their own group, as sharded_bench does; run_pipelined builds the
+            # next chunk's plan on a side stream while the current chunk's kernels run
+            tr = S.ShardedTrainer(shard, n_rows, tt, margin=0.2, seed=13, plan_group=dist.new_group())
             # step s uses rows [(s*world + rank)*B, +B) of the triple array
             mine = torch.stack([torch.as_tensor(tri[(s * world + rank) * B:(s * world + rank + 1) * B])
                                 for s in range(steps)], 0).cuda()
-            first = tr.run(mine[:steps - 1], lambda gs: 0.1)          # one planned chunk ...
-            last = tr.step(mine[steps - 1], lr=0.1)                   # ... then a single step
+            first = tr.run_pipelined([mine[s:s + 1] for s in range(steps - 1)], lambda gs: 0.1)   # pipelined chunks ...
+            last = tr.step(mine[steps - 1], lr=0.1)                                               # ... then a single step
             out = tr.gather_full_table()
             torch.cuda.synchronize()
             if rank == 0:

@@ -140,7 +140,7 @@ def test_fb15k_scale_ranks_match_oracle_on_real_id_files():
         rp, fp = [], []
         O.eval_link_prediction(s, triples, true, O.triple_dict([[h, t, r]]), rp, fp)
         assert [raw[i]] == rp and [fil[i]] == fp
-    m = E.score_mrr(raw, fil, verbose=False)
+    m = E.mrr_and_hits(raw, fil)
     assert 0 < m["filtered_mrr"] <= 1 and m["filtered_mrr"] >= m["raw_mrr"]
 
 

@@ -97,13 +97,14 @@ def _worker(rank, world, port, q):
         tt = SimpleNamespace(id_to_type=id_to_type, type_offsets=offsets, type_ids=type_ids, padded_size=32)
         full = torch.as_tensor(table)
         tr = S.ShardedTrainer(S.shard_rows(full, rank, world), full.shape[0], tt, margin=0.2, seed=9,
-                              kernels=OracleKernels())
+                              kernels=OracleKernels(), plan_group=dist.new_group())
         B = len(pos)
         mine = torch.as_tensor(pos[rank * B // world:(rank + 1) * B // world])
-        # one planned chunk of 2 steps (ids / counts / remaps exchanged once for both), then a single
-        # step: updates of earlier steps must be visible to later fetches
-        chunk = tr.run(torch.stack([mine, mine], 0), lambda gs: 0.05)
-        losses = [chunk[0], chunk[1], tr.step(mine, lr=0.05)]
+        # two pipelined chunks of one step each (the second chunk's plan is built right after the first
+        # chunk's steps are issued, on its own process group), then a single step: updates of earlier
+        # steps must be visible to later fetches
+        l01 = tr.run_pipelined([mine[None], mine[None]], lambda gs: 0.05)
+        losses = [l01[0], l01[1], tr.step(mine, lr=0.05)]
         out = tr.gather_full_table()
         mean = tr.mean_loss(losses[-1])
         if rank == 0:
