@@ -1,0 +1,270 @@
+// ge_rank.hip -- link-prediction ranks straight out of the candidate sweep (holE.py:427-472, 564-575).
+//
+// The reference scores one (head, relation) against every candidate tail, pushes (loss, triple) on a
+// heap and pops it in ascending order: raw rank = pops until the true tail, filtered rank = the same
+// without known-true candidates.  Equivalently, for test row i with true candidate c*:
+//     raw_i      = 1 + #{c : (E_ic, id_c) < (E_ic*, id_c*)}        (lexicographic: loss, then entity id)
+//     filtered_i = raw_i - #{known-true c != c* counted above}.
+// ge_complex_score_1vK + host code materialises all B x K losses to do this (883 M floats per side for
+// the FB15k test set).  Here the counting is the GEMM's epilogue and no score is ever stored.
+//
+// Structure (CDNA4): one 256-thread workgroup per (row block of 128 test rows, column split); it keeps
+// its Q operand -- q = clip-free fixed o relation, the whole k range, [Re q | Im q] -- in LDS for its
+// entire life (128 x 201 floats = 103 KB of the CU's 160 KB) and sweeps its share of the 128-wide
+// candidate tiles.  Per tile only the candidate rows move: 32-float chunks of the raw table rows
+// (score = [Re q | Im q] . [Re t | Im t], the row exactly as stored), double-buffered through LDS while
+// v_mfma_f32_32x32x2_f32 (exact fp32) runs on the previous chunk; d = 200 is 6 chunks + 8 floats, no k
+// padding.  Row strides 201 / 33 floats are odd: the 32 rows a half-wave reads hit 32 banks.
+// The true candidate's loss comes from the SAME tile code (a "diagonal" tile whose candidate rows are the
+// 128 true entities), so equal losses are bitwise equal and ties break by id exactly as the heap does.
+// Epilogue per tile: sigmoid, compare, one ballot per accumulator register -> a 128 x 128 bit mask in
+// LDS; a thread per row pop-counts it (raw), and the tile's (row, col) list of known-true candidates,
+// prepared by the host, is looked up in the same mask (filtered).
+#include "ge_common.h"
+
+namespace ge {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kRB = 128;          // rows per workgroup, columns per tile
+constexpr int kChunk = 32;        // reals per staged B chunk
+constexpr int kLdb = kChunk + 1;  // odd LDS stride
+
+struct RankLds {
+  float* A;        // [kRB][lda]
+  float* Bs;       // [2][kRB][kLdb]
+  float* sA;       // [kRB] product of the fixed row's and the relation row's clip scales (NaN: bad ids)
+  float* sB;       // [kRB] candidate clip scale (NaN: bad id)
+  float* eT;       // [kRB] loss of the true candidate
+  unsigned* bm;    // [kRB][4] `before` bits of the current tile
+  int* skip;       // [kRB] known-true candidates ranked before the target
+  int* tI;         // [kRB] entity id of the true candidate (-1 beyond B)
+};
+
+// One 128 x 128 tile: acc = Q . T^T for the candidate rows `cid` (this thread stages row t>>1, half t&1),
+// candidate clip scales to lds.sB.  Identical instruction sequence for every tile, diagonal tile included.
+__device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64_t N, int d, int lda,
+                                          int32_t cid, float max_norm, const RankLds& lds,
+                                          f32x16 (&acc)[2][2]) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int srow = t >> 1, half = t & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool bad = cid < 0 || cid >= N;
+  const float* crow = table + (int64_t)(bad ? 0 : cid) * d;
+  const int n_chunks = (d + kChunk - 1) / kChunk;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  float ss = 0.f;
+  float4 r[4];
+  auto fetch = [&](int ch) {
+    const int c0 = ch * kChunk + half * 16;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c = c0 + 4 * v;
+      r[v] = (!bad && c + 3 < d) ? *reinterpret_cast<const float4*>(crow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&](int buf) {
+    float* dst = lds.Bs + (buf * kRB + srow) * kLdb + half * 16;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      dst[4 * v] = r[v].x; dst[4 * v + 1] = r[v].y; dst[4 * v + 2] = r[v].z; dst[4 * v + 3] = r[v].w;
+      ss += r[v].x * r[v].x + r[v].y * r[v].y + r[v].z * r[v].z + r[v].w * r[v].w;
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < n_chunks) fetch(ch + 1);                       // global loads fly under the MFMAs
+    const int kmax = min(kChunk, d - ch * kChunk);               // 32, or the 8-float tail at d = 200
+    const float* ap = lds.A + (wm * 64 + li) * lda + ch * kChunk + lh;
+    const float* bp = lds.Bs + (buf * kRB + wn * 64 + li) * kLdb + lh;
+    for (int kk = 0; kk < kmax; kk += 2) {
+      const float a0 = ap[kk], a1 = ap[32 * lda + kk];
+      const float b0 = bp[kk], b1 = bp[32 * kLdb + kk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (ch + 1 < n_chunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+  ss += __shfl_xor(ss, 1, kWave);
+  if (half == 0) {
+    float inv;
+    lds.sB[srow] = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv);
+  }
+  __syncthreads();
+}
+
+// grid (column splits, row blocks).  known_off [n_row_blocks * n_col_tiles + 1], known_rc: (row_local << 7 |
+// col_local) of the known-true candidates of each (row block, column tile), may be null.
+__global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
+    const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
+    int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
+    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
+    float* __restrict__ scores_out, int lda) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  RankLds lds;
+  lds.A = smem;
+  lds.Bs = lds.A + kRB * lda;
+  lds.sA = lds.Bs + 2 * kRB * kLdb;
+  lds.sB = lds.sA + kRB;
+  lds.eT = lds.sB + kRB;
+  lds.bm = reinterpret_cast<unsigned*>(lds.eT + kRB);
+  lds.skip = reinterpret_cast<int*>(lds.bm + kRB * 4);
+  lds.tI = lds.skip + kRB;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int srow = t >> 1, half = t & 1;
+  const int k = d >> 1;
+  const int64_t m0 = (int64_t)blockIdx.y * kRB;
+  const int n_ct = (int)((K + kRB - 1) / kRB);
+
+  // ---- Q = fixed o relation for this block's rows, whole k range, kept in LDS for the sweep
+  {
+    const int64_t r = m0 + srow;
+    int32_t fid = -1, rid = -1;
+    if (r < B) { fid = hr[2 * r]; rid = hr[2 * r + 1]; }
+    const bool bad = fid < 0 || fid >= N || rid < 0 || rid >= N;
+    const float* frow = table + (int64_t)(bad ? 0 : fid) * d;
+    const float* rrow = table + (int64_t)(bad ? 0 : rid) * d;
+    float ssf = 0.f, ssr = 0.f;
+    float* arow = lds.A + srow * lda;
+    const int kh = (k + 1) / 2;                                  // complex dims per staging thread
+    for (int c = half * kh; c < min(k, (half + 1) * kh); ++c) {
+      const float fre = bad ? 0.f : frow[c], fim = bad ? 0.f : frow[k + c];
+      const float rre = bad ? 0.f : rrow[c], rim = bad ? 0.f : rrow[k + c];
+      ssf += fre * fre + fim * fim;
+      ssr += rre * rre + rim * rim;
+      float qre, qim;
+      if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
+        qre = fre * rre - fim * rim;
+        qim = fre * rim + fim * rre;
+      } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
+        qre = rre * fre + rim * fim;
+        qim = -(rim * fre - rre * fim);
+      }
+      arow[c] = qre;
+      arow[k + c] = qim;
+    }
+    ssf += __shfl_xor(ssf, 1, kWave);
+    ssr += __shfl_xor(ssr, 1, kWave);
+    if (half == 0) {
+      float i0, i1;
+      lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+      lds.skip[srow] = 0;
+      lds.tI[srow] = r < B ? true_id[r] : -1;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+  // ---- the true candidates' losses: a tile whose candidate rows are this block's 128 true entities
+  {
+    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, acc);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const int cl = wn * 64 + tn * 32 + li;
+          if (rl == cl) lds.eT[rl] = sigmoidf_dev(acc[tm][tn][q] * lds.sA[rl] * lds.sB[cl]);
+        }
+      }
+    __syncthreads();
+    if (true_loss && blockIdx.x == 0 && t < kRB && m0 + t < B) true_loss[m0 + t] = lds.eT[t];
+  }
+  int raw_reg = 0;
+
+  // ---- the sweep over this split's candidate tiles
+  for (int ct = blockIdx.x; ct < n_ct; ct += gridDim.x) {
+    const int64_t n0 = (int64_t)ct * kRB;
+    const int64_t c = n0 + srow;
+    const int32_t cid = c < K ? cand[c] : -1;
+    rank_tile(table, N, d, lda, cid, max_norm, lds, acc);
+    // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cl = wn * 64 + tn * 32 + li;
+      const int64_t col = n0 + cl;
+      const float sb = lds.sB[cl];
+      const int32_t cand_c = col < K ? cand[col] : -1;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+          const float e = sigmoidf_dev(acc[tm][tn][q] * lds.sA[rl] * sb);
+          const float et = lds.eT[rl];
+          const int64_t row = m0 + rl;
+          const bool before = col < K && row < B && (e < et || (e == et && cand_c < lds.tI[rl]));
+          const unsigned long long mask = __ballot(before);
+          if (li == 0) lds.bm[rl * 4 + wn * 2 + tn] = (unsigned)(mask >> (32 * lh));
+          if (scores_out && col < K && row < B) scores_out[row * K + col] = e;
+        }
+    }
+    __syncthreads();
+    if (t < kRB) {
+      const unsigned* m = lds.bm + t * 4;
+      raw_reg += __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+    }
+    if (known_off) {
+      const int64_t tile = (int64_t)blockIdx.y * n_ct + ct;
+      const int32_t e0 = known_off[tile], e1 = known_off[tile + 1];
+      for (int32_t e = e0 + t; e < e1; e += kBlock) {
+        const unsigned rc = known_rc[e];
+        const int rl = rc >> 7, cl = rc & 127;
+        if ((lds.bm[rl * 4 + (cl >> 5)] >> (cl & 31)) & 1u) atomicAdd(&lds.skip[rl], 1);
+      }
+    }
+    __syncthreads();
+  }
+  if (t < kRB && m0 + t < B) {
+    atomicAdd(&raw_cnt[m0 + t], raw_reg);
+    if (lds.skip[t]) atomicAdd(&skip_cnt[m0 + t], lds.skip[t]);
+  }
+}
+
+static size_t rank_lds_bytes(int d) {
+  const int lda = d + 1;
+  return sizeof(float) * ((size_t)kRB * lda + 2 * kRB * kLdb + 3 * kRB) + sizeof(unsigned) * kRB * 4 + sizeof(int) * 2 * kRB;
+}
+
+int rank_max_dim() { return 232; }   // Q (128 x (d+1) floats) + two candidate chunks must fit the CU's 160 KiB
+
+int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
+                            const int32_t* true_id, const int32_t* cand, int64_t K, float max_norm, int cand_is_head,
+                            const int32_t* known_off, const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt,
+                            float* true_loss, float* scores_out, hipStream_t st) {
+  if (d <= 0 || (d & 7)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;   // 16-byte candidate loads, 8-float tail
+  if (d > rank_max_dim()) return GE_ENOTSUP;
+  if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
+  if (B == 0 || K == 0) return 0;
+  const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
+  if (n_rb > 65535) return GE_ENOTSUP;
+  // column splits: enough workgroups for ~4 waves of the 256 CUs, never more than column tiles
+  int64_t splits = (4 * 256 + n_rb - 1) / n_rb;
+  if (splits > n_ct) splits = n_ct;
+  if (splits < 1) splits = 1;
+  const size_t lds = rank_lds_bytes(d);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_1vK_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(rank_1vK_kernel, dim3((unsigned)splits, (unsigned)n_rb), dim3(kBlock), lds, st, table, N, d, hr, B,
+                     true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss,
+                     scores_out, d + 1);
+  return launch_status();
+}
+
+}  // namespace ge

@@ -181,6 +181,25 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
                          const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
                          int cand_is_head, float* out, void* stream);
 
+/* --- link-prediction ranks straight out of the candidate sweep (holE.py:427-472 applied to the sweep of
+ * holE.py:564-575): for test row i = (fixed entity, relation) = hr[i] with true candidate entity true_id[i]
+ * (which must be in `cand`), over the K candidates,
+ *     n_before[i]       = #{c : (E_ic, id_c) < (E_i,true, true_id[i])}   -- ascending loss, ties by entity id,
+ *                         the pop order of the reference's heap; raw rank = 1 + n_before
+ *     n_known_before[i] = how many of those are known-true candidates; filtered rank = raw - n_known_before.
+ * The known-true candidates are given per (block of 128 test rows, tile of 128 candidates): known_off
+ * [ceil(B/128) * ceil(K/128) + 1] int32 offsets into known_rc, whose entries are (row % 128) << 7 | (column % 128)
+ * (both NULL: no filtering).  No [B,K] score matrix is written: the counting is the epilogue of the fp32-MFMA
+ * GEMM (E = sigmoid(score) as in ge_complex_score_1vK).  true_loss (nullable) [B] receives E_i,true;
+ * scores_out (nullable) [B,K] receives every loss -- for tests.  d must be a multiple of 8 and <= ge_rank_max_dim()
+ * (the block's Q operand lives in LDS for the whole sweep), table 16-byte aligned; otherwise GE_ENOTSUP and the
+ * caller falls back to ge_complex_score_1vK. */
+int ge_rank_max_dim(void);
+int ge_complex_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                        const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
+                        const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
+                        float* scores_out, void* stream);
+
 /* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
  * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already
  * shuffled [T,3] int32 array, wrapping to row 0 when the next batch would run past T -- the
