@@ -29,72 +29,108 @@ def mrr_and_hits(raw_ranks, filtered_ranks) -> dict:
             "hits1": pct(1), "hits3": pct(3), "hits10": pct(10)}
 
 
-def _known_lists(known_triples: np.ndarray, side: str):
-    """{(fixed entity, relation): sorted candidate ids known to be true} from [T,3] (h,t,r)."""
-    d = defaultdict(set)
-    if known_triples is None:
-        return d
-    for h, t, r in np.asarray(known_triples):
-        if side == "tail":
-            d[(int(h), int(r))].add(int(t))
-        else:
-            d[(int(t), int(r))].add(int(h))
-    return {k: sorted(v) for k, v in d.items()}
+class KnownIndex:
+    """Known-true triples as a device-side sorted index: key = fixed entity * n_rows + relation -> the entities
+    that complete a known triple (tails for side="tail", heads for "head")."""
+
+    def __init__(self, known_triples, n_rows: int, side: str, device):
+        self.n_rows = int(n_rows)
+        if known_triples is None or len(known_triples) == 0:
+            self.key = torch.empty(0, dtype=torch.int64, device=device)
+            self.ent = torch.empty(0, dtype=torch.int64, device=device)
+            return
+        k = torch.as_tensor(np.asarray(known_triples, dtype=np.int64)).to(device)
+        fixed, other = (k[:, 0], k[:, 1]) if side == "tail" else (k[:, 1], k[:, 0])
+        pairs = torch.unique(torch.stack([fixed * self.n_rows + k[:, 2], other], 1), dim=0)   # a set, like the
+        self.key, self.ent = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()                 # reference's dict of sets; sorted
+
+    def cells(self, fixed: torch.Tensor, rel: torch.Tensor, pos_of: torch.Tensor, n_cand: int):
+        """(row, candidate position) of every known-true candidate of the query rows, as the per-tile lists
+        ge_complex_rank_1vK takes: (known_off int32 [tiles+1], known_rc int16)."""
+        B = fixed.numel()
+        dev = fixed.device
+        n_ct = (n_cand + 127) // 128
+        n_tiles = ((B + 127) // 128) * n_ct
+        q = fixed.to(torch.int64) * self.n_rows + rel.to(torch.int64)
+        lo = torch.searchsorted(self.key, q)
+        cnt = torch.searchsorted(self.key, q, right=True) - lo
+        total = int(cnt.sum())
+        if total == 0:
+            return torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int16, device=dev)
+        start = torch.cumsum(cnt, 0) - cnt
+        row = torch.repeat_interleave(torch.arange(B, device=dev), cnt)
+        ent = self.ent[lo[row] + (torch.arange(total, device=dev) - start[row])]
+        col = pos_of[ent]
+        ok = col >= 0
+        row, col = row[ok], col[ok]
+        tile = (row // 128) * n_ct + col // 128
+        tile, order = torch.sort(tile)
+        rc = ((row[order] % 128) * 128 + col[order] % 128).to(torch.int16)
+        off = torch.searchsorted(tile, torch.arange(n_tiles + 1, device=dev)).to(torch.int32)
+        if rc.numel() == 0:
+            rc = torch.zeros(1, dtype=torch.int16, device=dev)
+        return off, rc
 
 
 @torch.no_grad()
 def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, candidates: np.ndarray,
-                          known_triples: np.ndarray = None, side: str = "tail", batch: int = 2048,
-                          max_norm: float = 1.0):
+                          known_triples: np.ndarray = None, side: str = "tail", batch: int = 16384,
+                          max_norm: float = 1.0, fused: bool = None):
     """Raw and filtered rank of every test triple's true entity among `candidates`, with the
     semantics of holE.py:446-469.  side="tail": candidates replace the tail; "head": the head.
-    Returns (raw_ranks, filtered_ranks) int64 arrays.  The true entity must be a candidate."""
+    Returns (raw_ranks, filtered_ranks) int64 arrays.  The true entity must be a candidate.
+    fused (default: whenever the kernel supports embedding_dim): the ranks are counted in the candidate
+    GEMM's epilogue (ge_complex_rank_1vK) and no [B,K] score matrix is materialised; otherwise the scores
+    of ge_complex_score_1vK are ranked with tensor ops."""
     assert side in ("tail", "head")
+    dev = embeddings.device
+    d = embeddings.shape[1]
+    if fused is None:
+        fused = d % 8 == 0 and d <= H.rank_max_dim()
     test = np.asarray(test_triples, dtype=np.int64)
-    cand = torch.as_tensor(np.asarray(candidates, dtype=np.int32)).to(embeddings.device)
+    cand = torch.as_tensor(np.asarray(candidates, dtype=np.int32)).to(dev)
     cand64 = cand.to(torch.int64)
     # position of every row id in the candidate list (-1: not a candidate)
-    pos_of = torch.full((embeddings.shape[0],), -1, dtype=torch.int64, device=embeddings.device)
-    pos_of[cand64] = torch.arange(cand.numel(), device=embeddings.device)
-    known = _known_lists(known_triples, side)
+    pos_of = torch.full((embeddings.shape[0],), -1, dtype=torch.int64, device=dev)
+    pos_of[cand64] = torch.arange(cand.numel(), device=dev)
+    index = KnownIndex(known_triples, embeddings.shape[0], side, dev)
     raw_all, fil_all = [], []
     fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
     for s in range(0, len(test), batch):
-        chunk = test[s:s + batch]
-        hr = torch.as_tensor(np.stack([chunk[:, fixed_col], chunk[:, 2]], 1).astype(np.int32)).to(embeddings.device)
-        true_id = torch.as_tensor(chunk[:, true_col]).to(embeddings.device)
-        scores = H.score_candidates(embeddings, hr, cand, cand_is_head=(side == "head"), max_norm=max_norm)
+        chunk = torch.as_tensor(test[s:s + batch]).to(dev)
+        fixed, rel, true_id = chunk[:, fixed_col], chunk[:, 2], chunk[:, true_col]
+        hr = torch.stack([fixed, rel], 1).to(torch.int32)
         tpos = pos_of[true_id]
         if (tpos < 0).any():
             raise ValueError("a test triple's true entity is not in the candidate list")
-        s_true = scores.gather(1, tpos.view(-1, 1))
-        # ascending by (loss, triple tuple): among equal losses the smaller entity id pops first
-        before = (scores < s_true) | ((scores == s_true) & (cand64.view(1, -1) < true_id.view(-1, 1)))
-        raw = before.sum(1) + 1
-        # filtered: known-true candidates popped before the target do not advance the rank
-        rows, cols = [], []
-        for i, (f, r) in enumerate(zip(chunk[:, fixed_col], chunk[:, 2])):
-            lst = known.get((int(f), int(r)))
-            if lst:
-                rows.extend([i] * len(lst))
-                cols.extend(lst)
-        if rows:
-            rows_t = torch.as_tensor(rows, device=embeddings.device)
-            cpos = pos_of[torch.as_tensor(cols, device=embeddings.device)]
-            ok = cpos >= 0
-            rows_t, cpos = rows_t[ok], cpos[ok]
-            hit = before[rows_t, cpos] & (cpos != tpos[rows_t])
-            skipped = torch.zeros(len(chunk), dtype=torch.int64, device=embeddings.device)
-            skipped.index_add_(0, rows_t, hit.to(torch.int64))
-            fil = raw - skipped
+        off, rc = index.cells(fixed, rel, pos_of, cand.numel())
+        if fused:
+            n_before, n_known = H.rank_candidates(embeddings, hr, true_id, cand, known_off=off, known_rc=rc,
+                                                  cand_is_head=(side == "head"), max_norm=max_norm)
+            raw = n_before.to(torch.int64) + 1
+            fil = raw - n_known.to(torch.int64)
         else:
-            fil = raw.clone()
+            scores = H.score_candidates(embeddings, hr, cand, cand_is_head=(side == "head"), max_norm=max_norm)
+            s_true = scores.gather(1, tpos.view(-1, 1))
+            # ascending by (loss, triple tuple): among equal losses the smaller entity id pops first
+            before = (scores < s_true) | ((scores == s_true) & (cand64.view(1, -1) < true_id.view(-1, 1)))
+            raw = before.sum(1) + 1
+            # filtered: known-true candidates popped before the target do not advance the rank
+            n_ct = (cand.numel() + 127) // 128
+            tiles = torch.repeat_interleave(torch.arange(off.numel() - 1, device=dev), (off[1:] - off[:-1]).to(torch.int64))
+            rcv = rc[:tiles.numel()].to(torch.int64)
+            rows_t = (tiles // n_ct) * 128 + rcv // 128
+            cols_t = (tiles % n_ct) * 128 + rcv % 128
+            skipped = torch.zeros(chunk.shape[0], dtype=torch.int64, device=dev)
+            if rows_t.numel():
+                skipped.index_add_(0, rows_t, before[rows_t, cols_t].to(torch.int64))
+            fil = raw - skipped
         raw_all.append(raw.cpu().numpy())
         fil_all.append(fil.cpu().numpy())
     return np.concatenate(raw_all), np.concatenate(fil_all)
 
 
-def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True, batch: int = 2048,
+def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True, batch: int = 16384,
                          verbose: bool = True) -> dict:
     """Filtered link prediction over all entities (rows >= relation_count) for
     data.test_array, filtering train+valid triples as the reference does (holE.py:413-422)."""

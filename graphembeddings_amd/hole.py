@@ -345,6 +345,51 @@ def score_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor,
     return out
 
 
+def rank_max_dim() -> int:
+    return int(_lib.load().ge_rank_max_dim())
+
+
+def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, true_ids: torch.Tensor,
+                    candidates: torch.Tensor, *, known_off: Optional[torch.Tensor] = None,
+                    known_rc: Optional[torch.Tensor] = None, cand_is_head: bool = False, max_norm: float = 1.0,
+                    return_true_loss: bool = False, return_scores: bool = False):
+    """The candidate sweep of holE.py:564-569 with the ranking of holE.py:427-472 as its epilogue
+    (ge_complex_rank_1vK): per test row the number of candidates that pop from the reference's heap before the
+    true one (n_before; raw rank = 1 + n_before) and how many of those are known-true (n_known_before; filtered
+    rank = raw - n_known_before).  No [B,K] score matrix exists unless return_scores asks for it (tests).
+    known_off / known_rc: the per-(128 rows x 128 candidates)-tile lists of known-true cells (evaluate.py)."""
+    emb = _table(embeddings)
+    for name, t in (("fixed_and_relation", fixed_and_relation), ("true_ids", true_ids), ("candidates", candidates)):
+        _need_cuda(t, name)
+    hr = fixed_and_relation.to(torch.int32).contiguous()
+    tid = true_ids.to(torch.int32).contiguous().view(-1)
+    cand = candidates.to(torch.int32).contiguous().view(-1)
+    B, K = hr.shape[0], cand.numel()
+    if hr.dim() != 2 or hr.shape[1] != 2 or tid.numel() != B:
+        raise ValueError("fixed_and_relation must be [B,2] (entity, relation) and true_ids [B]")
+    n_before = torch.empty(B, dtype=torch.int32, device=emb.device)
+    n_known = torch.empty(B, dtype=torch.int32, device=emb.device)
+    tl = torch.empty(B, dtype=torch.float32, device=emb.device) if return_true_loss else None
+    sc = torch.empty(B, K, dtype=torch.float32, device=emb.device) if return_scores else None
+    if (known_off is None) != (known_rc is None):
+        raise ValueError("known_off and known_rc come together")
+    if known_off is not None:
+        n_tiles = ((B + 127) // 128) * ((K + 127) // 128)
+        if known_off.dtype != torch.int32 or known_off.numel() != n_tiles + 1 or known_rc.dtype != torch.int16:
+            raise ValueError("known_off must be int32 [tiles+1], known_rc int16 (row%128 << 7 | col%128)")
+    _lib.call("ge_complex_rank_1vK", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), B, tid.data_ptr(),
+              cand.data_ptr(), K, max_norm, int(cand_is_head),
+              known_off.data_ptr() if known_off is not None else None,
+              known_rc.data_ptr() if known_rc is not None else None, n_before.data_ptr(), n_known.data_ptr(),
+              tl.data_ptr() if tl is not None else None, sc.data_ptr() if sc is not None else None, _stream())
+    out = (n_before, n_known)
+    if return_true_loss:
+        out += (tl,)
+    if return_scores:
+        out += (sc,)
+    return out
+
+
 class Trainer:
     """The inner loop of run_training (holE.py:340-362, minus validation) enqueued natively by
     ge_train_steps: per step a batch of the device-resident shuffled triple array, type-safe
