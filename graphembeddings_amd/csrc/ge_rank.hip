@@ -30,16 +30,45 @@ constexpr int kRB = 128;          // rows per workgroup, columns per tile
 constexpr int kChunk = 32;        // reals per staged B chunk
 constexpr int kLdb = kChunk + 1;  // odd LDS stride
 
+// sigmoid for the ranking epilogue: 4 VALU instructions (v_exp_f32, v_rcp_f32; ~2 ulp), used for EVERY loss this
+// kernel forms -- candidates and true entities alike -- so comparisons are self-consistent; within 1e-6 of
+// sigmoidf_dev, well inside the 1e-5 score bar.
+__device__ __forceinline__ float rank_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+
 struct RankLds {
   float* A;        // [kRB][lda]
   float* Bs;       // [2][kRB][kLdb]
-  float* sA;       // [kRB] product of the fixed row's and the relation row's clip scales (NaN: bad ids)
+  float* sA;       // [kRB] (unused: the fixed x relation clip scale is folded into A)
   float* sB;       // [kRB] candidate clip scale (NaN: bad id)
   float* eT;       // [kRB] loss of the true candidate
   unsigned* bm;    // [kRB][4] `before` bits of the current tile
   int* skip;       // [kRB] known-true candidates ranked before the target
   int* tI;         // [kRB] entity id of the true candidate (-1 beyond B)
 };
+
+// STEPS k-pairs of one staged chunk, fully unrolled: with one wave per SIMD (the Q operand fills the LDS, so a CU
+// holds one workgroup) nothing else hides the LDS latency -- all 4*STEPS operand reads are visible to the
+// scheduler at once and run ahead of the MFMAs that consume them.
+template <int STEPS>
+__device__ __forceinline__ void rank_mma(const float* __restrict__ ap, const float* __restrict__ bp, int lda,
+                                         f32x16 (&acc)[2][2]) {
+  float a0[STEPS], a1[STEPS], b0[STEPS], b1[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    a0[s] = ap[2 * s]; a1[s] = ap[32 * lda + 2 * s];
+    b0[s] = bp[2 * s]; b1[s] = bp[32 * kLdb + 2 * s];
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead: the scheduler otherwise sinks them next to their MFMA
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+  }
+}
 
 // One 128 x 128 tile: acc = Q . T^T for the candidate rows `cid` (this thread stages row t>>1, half t&1),
 // candidate clip scales to lds.sB.  Identical instruction sequence for every tile, diagonal tile included.
@@ -85,13 +114,11 @@ __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64
     const int kmax = min(kChunk, d - ch * kChunk);               // 32, or the 8-float tail at d = 200
     const float* ap = lds.A + (wm * 64 + li) * lda + ch * kChunk + lh;
     const float* bp = lds.Bs + (buf * kRB + wn * 64 + li) * kLdb + lh;
-    for (int kk = 0; kk < kmax; kk += 2) {
-      const float a0 = ap[kk], a1 = ap[32 * lda + kk];
-      const float b0 = bp[kk], b1 = bp[32 * kLdb + kk];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    if (kmax == kChunk) {                                        // two halves: 64 operand registers in flight
+      rank_mma<8>(ap, bp, lda, acc);
+      rank_mma<8>(ap + 16, bp + 16, lda, acc);
+    } else {                                                     // the tail chunk: 8, 16 or 24 reals
+      for (int kk = 0; kk < kmax; kk += 8) rank_mma<4>(ap + kk, bp + kk, lda, acc);
     }
     if (ch + 1 < n_chunks) stash(buf ^ 1);
     __syncthreads();
@@ -140,11 +167,22 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     float ssf = 0.f, ssr = 0.f;
     float* arow = lds.A + srow * lda;
     const int kh = (k + 1) / 2;                                  // complex dims per staging thread
-    for (int c = half * kh; c < min(k, (half + 1) * kh); ++c) {
+    const int c_lo = half * kh, c_hi = min(k, (half + 1) * kh);
+    for (int c = c_lo; c < c_hi; ++c) {                          // pass 1: the two clip norms
       const float fre = bad ? 0.f : frow[c], fim = bad ? 0.f : frow[k + c];
       const float rre = bad ? 0.f : rrow[c], rim = bad ? 0.f : rrow[k + c];
       ssf += fre * fre + fim * fim;
       ssr += rre * rre + rim * rim;
+    }
+    ssf += __shfl_xor(ssf, 1, kWave);
+    ssr += __shfl_xor(ssr, 1, kWave);
+    float i0, i1;
+    // the product of the fixed row's and the relation row's clip scales is folded into Q (NaN: bad ids / beyond B,
+    // which makes every loss of the row NaN and every comparison false)
+    const float sa = (bad || r >= B) ? __builtin_nanf("") : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+    for (int c = c_lo; c < c_hi; ++c) {                          // pass 2: q = fixed o relation, scaled
+      const float fre = bad ? 0.f : frow[c], fim = bad ? 0.f : frow[k + c];
+      const float rre = bad ? 0.f : rrow[c], rim = bad ? 0.f : rrow[k + c];
       float qre, qim;
       if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
         qre = fre * rre - fim * rim;
@@ -153,14 +191,10 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
         qre = rre * fre + rim * fim;
         qim = -(rim * fre - rre * fim);
       }
-      arow[c] = qre;
-      arow[k + c] = qim;
+      arow[c] = qre * sa;
+      arow[k + c] = qim * sa;
     }
-    ssf += __shfl_xor(ssf, 1, kWave);
-    ssr += __shfl_xor(ssr, 1, kWave);
     if (half == 0) {
-      float i0, i1;
-      lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
       lds.skip[srow] = 0;
       lds.tI[srow] = r < B ? true_id[r] : -1;
     }
@@ -169,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
 
   f32x16 acc[2][2];
   // ---- the true candidates' losses: a tile whose candidate rows are this block's 128 true entities
+  float et[2][16];     // E of the true candidate of each of this lane's 32 accumulator rows, for the whole sweep
   {
     rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, acc);
 #pragma unroll
@@ -179,10 +214,14 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
           const int cl = wn * 64 + tn * 32 + li;
-          if (rl == cl) lds.eT[rl] = sigmoidf_dev(acc[tm][tn][q] * lds.sA[rl] * lds.sB[cl]);
+          if (rl == cl) lds.eT[rl] = rank_sigmoid(acc[tm][tn][q] * lds.sB[cl]);
         }
       }
     __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) et[tm][q] = lds.eT[wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh];
     if (true_loss && blockIdx.x == 0 && t < kRB && m0 + t < B) true_loss[m0 + t] = lds.eT[t];
   }
   int raw_reg = 0;
@@ -193,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     const int64_t c = n0 + srow;
     const int32_t cid = c < K ? cand[c] : -1;
     rank_tile(table, N, d, lda, cid, max_norm, lds, acc);
-    // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // A candidate beyond K or with a bad id has a NaN clip scale, a row beyond B a NaN Q: every comparison false.
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int cl = wn * 64 + tn * 32 + li;
@@ -204,14 +244,13 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+          const float e = rank_sigmoid(acc[tm][tn][q] * sb);
+          unsigned long long mask = __ballot(e < et[tm][q]);
+          const unsigned long long ties = __ballot(e == et[tm][q]);
           const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-          const float e = sigmoidf_dev(acc[tm][tn][q] * lds.sA[rl] * sb);
-          const float et = lds.eT[rl];
-          const int64_t row = m0 + rl;
-          const bool before = col < K && row < B && (e < et || (e == et && cand_c < lds.tI[rl]));
-          const unsigned long long mask = __ballot(before);
+          if (ties) mask |= __ballot(e == et[tm][q] && cand_c < lds.tI[rl]);     // equal losses pop in id order
           if (li == 0) lds.bm[rl * 4 + wn * 2 + tn] = (unsigned)(mask >> (32 * lh));
-          if (scores_out && col < K && row < B) scores_out[row * K + col] = e;
+          if (scores_out && col < K && m0 + rl < B) scores_out[(m0 + rl) * K + col] = e;
         }
     }
     __syncthreads();

@@ -101,8 +101,9 @@ def test_gpu_ranks_equal_reference_heap_semantics(fused):
 
 def test_fused_and_unfused_rankers_agree_at_fb15k_scale():
     """Full-width sweep (14,951 candidates, 117 column tiles, d = 200): the epilogue-counted ranks and the
-    ranks from stored scores differ only where two candidates' losses are within an ulp of each other in one
-    kernel and not the other (different k order); on random tables that is at most a rank or two, rarely."""
+    ranks from stored scores differ only where two candidates' losses are within a few ulps of each other in one
+    kernel and not the other (different k order, 4-instruction sigmoid in the epilogue); on random tables that
+    is a rank or two on a few percent of the rows."""
     from graphembeddings_amd import data as D
     from graphembeddings_amd import evaluate as E
     from graphembeddings_amd import hole as H
@@ -115,8 +116,8 @@ def test_fused_and_unfused_rankers_agree_at_fb15k_scale():
     for side in ("tail", "head"):
         r1, f1 = E.link_prediction_ranks(emb, test, cand, known, side=side, fused=True)
         r2, f2 = E.link_prediction_ranks(emb, test, cand, known, side=side, fused=False)
-        assert np.abs(r1 - r2).max() <= 2 and np.mean(r1 != r2) < 0.02
-        assert np.abs(f1 - f2).max() <= 2 and np.mean(f1 != f2) < 0.02
+        assert np.abs(r1 - r2).max() <= 3 and np.mean(r1 != r2) < 0.06
+        assert np.abs(f1 - f2).max() <= 3 and np.mean(f1 != f2) < 0.06
         assert (f1 <= r1).all() and (f1 >= 1).all()
 
 
