@@ -21,7 +21,7 @@ int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, 
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
 int bernoulli_corrupt_launch(const int32_t*, int64_t, const int64_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, const uint32_t*, int32_t, int32_t, int32_t, uint64_t, uint64_t, int32_t*, hipStream_t);
-int complex_logloss_grad_launch(const float*, int64_t, int32_t, const int32_t*, const float*, int64_t, float, float, float, const float*, float*, int32_t*, float*, hipStream_t);
+int complex_logloss_grad_launch(const float*, int64_t, int32_t, const int32_t*, const float*, int64_t, float, float, float, const float*, float*, int32_t*, float*, hipStream_t, const int32_t* negs = nullptr, int64_t B = 0, float row_scale = 1.f, float neg_lr_eff = 0.f, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int table_sumsq_launch(const float*, int64_t, float*, hipStream_t);
 int table_scale_launch(float*, int64_t, float, hipStream_t);
 size_t hinge_ws_bytes(int64_t, int32_t);
@@ -29,6 +29,8 @@ size_t train_ws_bytes(int64_t, int32_t);
 int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, void*, hipStream_t);
 int train_prepare_run(const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int, int32_t*, hipStream_t);
 void train_prepared_layout(int64_t, int64_t*);
+size_t train_logloss_ws_bytes(int64_t, int32_t, int32_t);
+int train_logloss_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t, float, float, float, float, float, float*, int, int32_t*, void*, size_t, void*, hipStream_t);
 int pipeline_create(void**);
 int pipeline_reset(void*);
 int pipeline_destroy(void*);
@@ -240,6 +242,29 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
                          type_ids, seed, global_step0, padded_size, mode, margin, lr0, decay_steps, decay_rate,
                          max_norm, model, loss, keep_all_losses, neg_ws, workspace, workspace_bytes, ev_pairs,
                          ev_kernel, pipeline, (hipStream_t)stream);
+}
+
+size_t ge_train_logloss_workspace_bytes(int64_t B, int32_t negative_ratio, int32_t d) {
+  if (B <= 0 || negative_ratio <= 0 || d <= 0) return 0;
+  return train_logloss_ws_bytes(B, negative_ratio, d);
+}
+
+int ge_train_steps_logloss(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,
+                           int64_t B, int64_t n_steps, const int32_t* id_to_type, const int64_t* type_offsets,
+                           int32_t n_types, const int32_t* type_ids, uint64_t seed, uint64_t global_step0,
+                           int32_t padded_size, int32_t mode, int32_t negative_ratio, float l2, float lr0,
+                           float decay_steps, float decay_rate, float max_norm, float* loss, int keep_all_losses,
+                           int32_t* neg_ws, void* workspace, size_t workspace_bytes, void* pipeline, void* stream) {
+  if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (negative_ratio <= 0 || negative_ratio > 1024 || (d & 1)) return GE_EINVAL;
+  if (!triples || !id_to_type || !type_offsets || !type_ids || !loss || !neg_ws || !workspace) return GE_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
+  if (mode < 0 || mode > 3 || padded_size < 0 || n_types < 0) return GE_EINVAL;
+  if ((int64_t)(1 + negative_ratio) * B > ((int64_t)1 << 24)) return GE_ENOTSUP;
+  return train_logloss_run(table, N, d, triples, T, first_row, B, n_steps, id_to_type, type_offsets, n_types, type_ids,
+                           seed, global_step0, padded_size, mode, negative_ratio, l2, lr0, decay_steps, decay_rate,
+                           max_norm, loss, keep_all_losses, neg_ws, workspace, workspace_bytes, pipeline,
+                           (hipStream_t)stream);
 }
 
 int ge_train_pipeline_create(void** pipeline) { return pipeline ? pipeline_create(pipeline) : GE_EINVAL; }

@@ -196,30 +196,44 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
 //     loss = log(1 + exp(-y s)) + l2 * l2_loss(table),   d loss/d s = -y sigma(-y s).
 // One group per triple; emits 3 IndexedSlices rows (h, t, r) already multiplied by -lr.  The dense
 // L2 term is handled by the caller (a whole-table scale, see ge_complex_logloss_step).
+// Two ways to name the M triples: (triples [M,3], labels [M]) -- the single-step entry point -- or, inside the
+// native loop (negs != null), positives `triples` [B,3] followed by negs [K*B,3] with labels +1 / -1 by position.
+// row_scale: the table holds rows / row_scale (the dense L2 decay of the step is kept as ONE scalar, see
+// train_logloss_run); loaded rows are multiplied by it and `neg_lr_eff` already carries the 1 / new-scale.
 template <int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_logloss_grad_kernel(
     const float* __restrict__ rows, int64_t N, int d, const int32_t* __restrict__ triples,
-    const float* __restrict__ labels, int64_t M, float lr, float max_norm, float l2,
-    const float* __restrict__ table_sumsq, float* __restrict__ loss, int32_t* __restrict__ grad_idx,
-    float* __restrict__ grad_val) {
+    const float* __restrict__ labels, const int32_t* __restrict__ negs, int64_t B, int64_t M, float neg_lr_eff,
+    float max_norm, float l2, float row_scale, const float* __restrict__ table_sumsq, float* __restrict__ loss,
+    int32_t* __restrict__ grad_idx, float* __restrict__ grad_val) {
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int k = d >> 1, nvec = k / VEC;
-  const float neg_lr = -lr;
-  const float reg = l2 * 0.5f * table_sumsq[0];   // l2 * tf.nn.l2_loss(embeddings), same for every row
+  // l2 * tf.nn.l2_loss(embeddings), same for every row of the loss vector (null: not asked for this step)
+  const float reg = table_sumsq ? l2 * 0.5f * row_scale * row_scale * table_sumsq[0] : 0.f;
   for (int64_t base = wave * GPW; base < M; base += nwaves * GPW) {
     const int64_t g = base + grp;
     const bool live = g < M;
     int32_t p[3] = {0, 0, 0};
     float y = 1.f;
-    if (live) { p[0] = triples[3 * g]; p[1] = triples[3 * g + 1]; p[2] = triples[3 * g + 2]; y = labels[g]; }
+    if (live) {
+      const int32_t* t3 = (negs && g >= B) ? negs + 3 * (g - B) : triples + 3 * g;
+      p[0] = t3[0]; p[1] = t3[1]; p[2] = t3[2];
+      y = negs ? (g < B ? 1.f : -1.f) : labels[g];
+    }
     const bool bad = bad3(N, p[0], p[1], p[2]);
     if (bad) { p[0] = p[1] = p[2] = 0; }
     Row<VEC, NITER> x[3];
 #pragma unroll
-    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, x[X]);
+    for (int X = 0; X < 3; ++X) {
+      load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, x[X]);
+#pragma unroll
+      for (int it = 0; it < NITER; ++it)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { x[X].re[it][v] *= row_scale; x[X].im[it][v] *= row_scale; }
+    }
     const SideFwd f = side_forward<false, VEC, LPT, NITER>(x[0], x[1], x[2], max_norm, false, 1.f);
     const float z = -y * f.s;                                            // holE.py:195
     const float softplus = z > 0.f ? z + log1pf(expf(-z)) : log1pf(expf(z));
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void complex_logloss_grad_kernel(
       const int64_t slot = g * 3 + X;
       if (live && sub == 0) grad_idx[slot] = bad ? -1 : p[X];
       if (!live || bad) continue;
-      const RowCoef kc = row_coef(coef, f, X, max_norm, neg_lr);
+      const RowCoef kc = row_coef(coef, f, X, max_norm, neg_lr_eff);
       float* gp = grad_val + slot * d;
 #pragma unroll
       for (int it = 0; it < NITER; ++it) {
@@ -377,15 +391,17 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
 int complex_logloss_grad_launch(const float* rows, int64_t N, int32_t d, const int32_t* triples,
                                 const float* labels, int64_t M, float lr, float max_norm, float l2,
                                 const float* table_sumsq, float* loss, int32_t* grad_idx, float* grad_val,
-                                hipStream_t st) {
+                                hipStream_t st, const int32_t* negs, int64_t B, float row_scale, float neg_lr_eff,
+                                hipEvent_t ev_start, hipEvent_t ev_stop) {
   Shape s;
   if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(grad_val) % (s.vec * 4)) != 0) return GE_EINVAL;
   if (M == 0) return 0;
+  if (!negs) neg_lr_eff = -lr;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(M, gpb);
 #define CALL(V, L, NI) \
-  hipLaunchKernelGGL((complex_logloss_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, rows, N, d, triples, labels, M, lr, max_norm, l2, table_sumsq, loss, grad_idx, grad_val)
+  hipExtLaunchKernelGGL((complex_logloss_grad_kernel<V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, triples, labels, negs, B, M, neg_lr_eff, max_norm, l2, row_scale, table_sumsq, loss, grad_idx, grad_val)
   GE_DISPATCH_SHAPE(s, 2, CALL);
 #undef CALL
   return launch_status();

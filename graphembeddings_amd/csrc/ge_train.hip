@@ -26,6 +26,7 @@
 // where the previous one stopped finds its records already built.  Without a handle the launches go
 // to the caller's stream (one ~20 us launch per chunk of steps) and the library keeps no state at all.
 #include "ge_common.h"
+#include <cmath>
 
 namespace ge {
 
@@ -54,21 +55,30 @@ __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_
 }
 
 // ------------------------------------------------------------------ prepared-step record (int32 words)
-//   neg[3B] | slot_item[6B] | pad to 64 | n_sub x { n_items, pad to 64 | items[4*S][2] | islots[4*S][16] }
-// S = pairs per sub-batch (min(B, 4096) rounded up to 256).  items[k] = {table row, count | multi << 30};
-// islots[k][0..16) = the IndexedSlices slots (6*pair + {0 h+,1 t+,2 r+,3 h-,4 t-,5 r-}) the item sums, -1 padded.
+// hinge (negs = 0):   neg[3B] | slot_item[6B] | pad to 64 | n_sub x { n_items, pad to 64 | items[P][2] | islots[P][16] }
+//   a UNIT is a (pos,neg) pair with 4 sort keys; slot = 6*pair + {0 h+,1 t+,2 r+,3 h-,4 t-,5 r-}.
+// log-loss (negs = K): neg[K][B][3] | pad to 64 | n_sub x { ... }
+//   a UNIT is one of the M = (1+K)B triples (positives first, then the K corrupted batches, holE.py:206-220)
+//   with 3 sort keys; slot = 3*triple + {0 h, 1 t, 2 r}.
+// S = units per sub-batch (<= 4096), P = keys per sub-batch (a multiple of 1024).  items[k] = {table row,
+// count | multi << 30}; islots[k][0..16) = the slots the item sums, -1 padded.
 struct PrepLayout {
-  int64_t B, n_sub, S, P, off_slot, off_sub, sub_stride, off_items, off_islots, stride;
+  int64_t B, negs, units, n_sub, S, P, off_slot, off_sub, sub_stride, off_items, off_islots, stride;
+  int epu;   // sort keys per unit
 };
-__host__ __device__ inline PrepLayout prep_layout(int64_t B) {
+__host__ __device__ inline PrepLayout prep_layout(int64_t B, int64_t negs = 0) {
   PrepLayout L;
   L.B = B;
-  L.n_sub = (B + kSub - 1) / kSub;
-  const int64_t s = B < kSub ? B : kSub;
-  L.S = (s + 255) / 256 * 256;
-  L.P = 4 * L.S;                       // sort keys per workgroup, a multiple of 1024
+  L.negs = negs;
+  L.epu = negs > 0 ? 3 : 4;
+  L.units = negs > 0 ? (1 + negs) * B : B;
+  L.n_sub = (L.units + kSub - 1) / kSub;
+  const int64_t s = L.units < kSub ? L.units : kSub;
+  const int64_t gran = negs > 0 ? 1024 : 256;          // P = epu * S must be a multiple of 1024
+  L.S = (s + gran - 1) / gran * gran;
+  L.P = L.epu * L.S;
   L.off_slot = 3 * B;
-  L.off_sub = (9 * B + 63) / 64 * 64;
+  L.off_sub = negs > 0 ? (3 * negs * B + 63) / 64 * 64 : (9 * B + 63) / 64 * 64;
   L.off_items = 64;
   L.off_islots = 64 + 2 * L.P;
   L.sub_stride = 64 + 2 * L.P + kItemCap * L.P;
@@ -92,9 +102,9 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0,
     const int32_t* __restrict__ id_to_type, int64_t N, const int64_t* __restrict__ type_offsets,
     int32_t n_types, const int32_t* __restrict__ type_ids, uint64_t seed, uint64_t global_step0,
-    int32_t padded_size, int32_t mode, int direct, int n_pass, int bits, int32_t* __restrict__ prep) {
+    int32_t padded_size, int32_t mode, int direct, int n_pass, int bits, int negs, int32_t* __restrict__ prep) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-  const PrepLayout L = prep_layout(B);
+  const PrepLayout L = prep_layout(B, negs);
   const int P = (int)L.P, R = P / kPrepThreads;   // R = keys per lane per wave segment (1..16)
   unsigned* hist = reinterpret_cast<unsigned*>(keys + P);
   int* wtot = reinterpret_cast<int*>(hist + kPrepWaves * kMaxRadix);
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
   int32_t* items = subrec + L.off_items;
   int32_t* islots = subrec + L.off_islots;
   const int64_t i0 = (int64_t)sub * kSub;
-  const int S = (int)((B - i0) < kSub ? (B - i0) : kSub);     // pairs of this sub-batch
+  const int S = (int)((L.units - i0) < kSub ? (L.units - i0) : kSub);     // units of this sub-batch
   const uint64_t step = global_step0 + (uint64_t)s;
   const bool batch_heads = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, step) : false;
   constexpr unsigned long long kInvalid = ~0ull;
@@ -117,7 +127,36 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
   if (direct)
     for (int i = tid; i < 6 * S; i += kPrepThreads) slot_item[6 * i0 + i] = -1;
 
-  // ---- phase 1: negatives + sort keys, in slot order (key index 4*pair + k  <->  ascending slot id)
+  // ---- phase 1: negatives + sort keys, in slot order (key index epu*unit + k  <->  ascending slot id)
+  if (negs > 0) {
+    // log-loss: unit j < B is positive j; unit B + k*B + i is positive i corrupted by the k-th corrupt_batch
+    // call of the step, whose Philox step key is global_step * K + k (its own coin, its own subsample)
+    for (int il = tid; il < (int)L.S; il += kPrepThreads) {
+      unsigned long long k3[3] = {kInvalid, kInvalid, kInvalid};
+      if (il < S) {
+        const int64_t j = i0 + il;
+        const int64_t i = j < B ? j : (j - B) % B;
+        int32_t t3[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+        if (j >= B) {
+          const int64_t kk = (j - B) / B;
+          const uint64_t stepk = step * (uint64_t)negs + (uint64_t)kk;
+          const bool heads_k = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, stepk) : false;
+          int col;
+          const int32_t repl = corrupt_one(t3, i, heads_k, id_to_type, N, type_offsets, n_types, type_ids, seed, stepk,
+                                           padded_size, mode, col);
+          t3[col] = repl;
+          int32_t* o = neg + 3 * (kk * B + i);
+          o[0] = t3[0]; o[1] = t3[1]; o[2] = t3[2];
+        }
+        const bool bad = t3[0] < 0 || t3[1] < 0 || t3[2] < 0 || t3[0] >= N || t3[1] >= N || t3[2] >= N;
+#pragma unroll
+        for (int X = 0; X < 3; ++X)
+          if (!bad) k3[X] = ((unsigned long long)(uint32_t)t3[X] << 32) | (uint32_t)(3 * j + X);
+      }
+#pragma unroll
+      for (int X = 0; X < 3; ++X) keys[3 * il + X] = k3[X];
+    }
+  } else
   for (int il = tid; il < (int)L.S; il += kPrepThreads) {
     if (il < S) {
       const int64_t i = i0 + il;
@@ -371,8 +410,9 @@ bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= (int64_t)1 << 2
 
 // steps prepared per launch: 32 at B <= 4096 (one record is ~1.2 MB there), fewer for large batches so
 // that a chunk stays near 40 MB
-static int64_t prep_chunk_steps(int64_t B) {
-  int64_t c = (32 * kSub) / (B < kSub ? kSub : B);
+static int64_t prep_chunk_steps(int64_t B, int64_t negs = 0) {
+  const int64_t u = negs > 0 ? (1 + negs) * B : B;
+  int64_t c = (32 * kSub) / (u < kSub ? kSub : u);
   return c < 2 ? 2 : c;
 }
 
@@ -398,8 +438,8 @@ static int grad_ring(int64_t B, int32_t d) {
 static size_t train_grad_bytes(int64_t B, int32_t d) {
   return align_up_sz(sizeof(int32_t) * 6 * (size_t)B, 256) + (size_t)grad_ring(B, d) * grad_region_bytes(B, d);
 }
-static size_t prep_chunk_bytes(int64_t B) {
-  return align_up_sz(sizeof(int32_t) * (size_t)prep_chunk_steps(B) * (size_t)prep_layout(B).stride, 256);
+static size_t prep_chunk_bytes(int64_t B, int64_t negs = 0) {
+  return align_up_sz(sizeof(int32_t) * (size_t)prep_chunk_steps(B, negs) * (size_t)prep_layout(B, negs).stride, 256);
 }
 size_t train_ws_bytes(int64_t B, int32_t d) {
   if (!train_fast_ok(B, d)) return hinge_ws_bytes(B, d);
@@ -413,8 +453,8 @@ static size_t prep_lds_bytes(const PrepLayout& L) {
 static int prepare_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n,
                           const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
                           const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
-                          int32_t mode, int direct, int32_t* out, hipStream_t st) {
-  const PrepLayout L = prep_layout(B);
+                          int32_t mode, int direct, int32_t* out, hipStream_t st, int negs = 0) {
+  const PrepLayout L = prep_layout(B, negs);
   int nbits = 1;
   while (((int64_t)1 << nbits) <= N) ++nbits;          // the value N itself (and above) is free for invalid keys
   const int n_pass = (nbits + 7) / 8;
@@ -427,7 +467,7 @@ static int prepare_launch(const int32_t* triples, int64_t T, int64_t first_row, 
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(train_prepare_kernel, dim3((unsigned)n, (unsigned)L.n_sub), dim3(kPrepThreads), lds, st, triples,
                      T, first_row, B, s0, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
-                     padded_size, mode, direct, n_pass, bits, out);
+                     padded_size, mode, direct, n_pass, bits, negs, out);
   return launch_status();
 }
 
@@ -446,7 +486,7 @@ struct Pipeline {
   int64_t T = 0, B = 0, N = 0, origin_row = 0, next_abs = 0, resident[2] = {-1, -1};
   uint64_t seed = 0, origin_gs = 0;
   int32_t n_types = 0, padded_size = 0, mode = 0, d = 0;
-  int direct = 0;
+  int direct = 0, negs = 0;
 };
 
 int pipeline_create(void** out) {
@@ -484,6 +524,118 @@ static inline int64_t norm_row(int64_t first_row, int64_t T, int64_t B) {
   return f;
 }
 
+// ------------------------------------------------------------------ walking the prepared records
+// Shared by the hinge and the log-loss loops: which chunk of steps each of the two workspace buffers holds,
+// when a prepare launch is due (on the handle's side stream, one chunk ahead, or on the caller's stream
+// without a handle) and where step s finds its record.
+struct StepIdentity {
+  const int32_t* triples; int64_t T, first_row, B; const int32_t* id_to_type; int64_t N;
+  const int64_t* type_offsets; int32_t n_types; const int32_t* type_ids; uint64_t seed, global_step0;
+  int32_t padded_size, mode, d; int direct, negs; void* workspace;
+};
+
+class PrepCursor {
+ public:
+  PrepCursor(const StepIdentity& id, Pipeline* handle, int32_t* prep_base, hipStream_t st)
+      : id_(id), L_(prep_layout(id.B, id.negs)), K_(prep_chunk_steps(id.B, id.negs)),
+        buf_ints_((int64_t)(prep_chunk_bytes(id.B, id.negs) / sizeof(int32_t))), base_(prep_base), st_(st),
+        pipe_(handle ? handle : &local_), own_side_(handle != nullptr) {}
+
+  int begin() {
+    if (own_side_) {
+      int dev = -1;
+      GE_HIP_TRY(hipGetDevice(&dev));
+      if (dev != pipe_->device) return GE_EINVAL;
+      Pipeline* p = pipe_;
+      const bool cont = p->live && p->triples == id_.triples && p->id_to_type == id_.id_to_type &&
+                        p->type_offsets == id_.type_offsets && p->type_ids == id_.type_ids &&
+                        p->workspace == id_.workspace && p->T == id_.T && p->B == id_.B && p->N == id_.N &&
+                        p->seed == id_.seed && p->n_types == id_.n_types && p->padded_size == id_.padded_size &&
+                        p->mode == id_.mode && p->d == id_.d && p->direct == id_.direct && p->negs == id_.negs &&
+                        id_.global_step0 == p->origin_gs + (uint64_t)p->next_abs &&
+                        norm_row(id_.first_row, id_.T, id_.B) == step_row(p->origin_row, id_.T, id_.B, p->next_abs);
+      if (!cont) {
+        p->live = true;
+        p->triples = id_.triples; p->id_to_type = id_.id_to_type; p->type_offsets = id_.type_offsets;
+        p->type_ids = id_.type_ids; p->workspace = id_.workspace; p->T = id_.T; p->B = id_.B; p->N = id_.N;
+        p->seed = id_.seed; p->n_types = id_.n_types; p->padded_size = id_.padded_size; p->mode = id_.mode;
+        p->d = id_.d; p->direct = id_.direct; p->negs = id_.negs;
+        p->origin_row = norm_row(id_.first_row, id_.T, id_.B); p->origin_gs = id_.global_step0; p->next_abs = 0;
+        p->resident[0] = p->resident[1] = -1;
+      }
+      base_abs_ = p->next_abs;
+    } else {
+      pipe_->origin_row = norm_row(id_.first_row, id_.T, id_.B);
+      pipe_->origin_gs = id_.global_step0;
+      pipe_->side = st_;
+    }
+    return 0;
+  }
+
+  // record of step s of this call (s ascending); launches / waits for prepare work as chunks are entered
+  int step(int64_t s, const int32_t** rec) {
+    const int64_t abs_s = base_abs_ + s, chunk = abs_s / K_, in_chunk = abs_s % K_;
+    if (s == 0 || in_chunk == 0) {
+      int rc = ensure(chunk);
+      if (rc) return rc;
+      // the next chunk is prepared on the side stream while this one trains -- also when it lies beyond
+      // this call's last step: the call that continues from there finds it done
+      if (own_side_) {
+        rc = ensure(chunk + 1);
+        if (rc) return rc;
+        GE_HIP_TRY(hipStreamWaitEvent(st_, pipe_->prep_done[chunk & 1], 0));
+      }
+    }
+    *rec = base_ + (chunk & 1) * buf_ints_ + in_chunk * L_.stride;
+    return 0;
+  }
+
+  // after the last step: the last record (for the caller's neg_ws) and the end-of-call ordering
+  int finish(int64_t n_steps, const int32_t** last_rec) {
+    const int64_t la = base_abs_ + n_steps - 1;
+    *last_rec = base_ + ((la / K_) & 1) * buf_ints_ + (la % K_) * L_.stride;
+    if (own_side_) {
+      // the look-ahead launch writes into the caller's workspace after this call returns: order it before
+      // whatever the caller enqueues on `st` next (e.g. a stream-ordered free of the workspace)
+      GE_HIP_TRY(hipStreamWaitEvent(st_, pipe_->prep_done[((la / K_) + 1) & 1], 0));
+      pipe_->next_abs = base_abs_ + n_steps;
+    }
+    return 0;
+  }
+
+  const PrepLayout& layout() const { return L_; }
+
+ private:
+  // chunk c of the sequence -> buffer c & 1.  Before a prepare launch overwrites a buffer, the side
+  // stream waits for everything enqueued on `st` so far: that includes every step of the chunk that
+  // held the buffer before, and (first launch) earlier work that may still be writing `triples`.
+  int ensure(int64_t c) {
+    const int b = (int)(c & 1);
+    if (pipe_->resident[b] == c) return 0;
+    if (own_side_) {
+      GE_HIP_TRY(hipEventRecord(pipe_->buf_free[b], st_));
+      GE_HIP_TRY(hipStreamWaitEvent(pipe_->side, pipe_->buf_free[b], 0));
+    }
+    int rc = prepare_launch(id_.triples, id_.T, pipe_->origin_row, id_.B, c * K_, K_, id_.id_to_type, id_.N,
+                            id_.type_offsets, id_.n_types, id_.type_ids, id_.seed, pipe_->origin_gs, id_.padded_size,
+                            id_.mode, id_.direct, base_ + b * buf_ints_, pipe_->side, id_.negs);
+    if (rc) return rc;
+    if (own_side_) GE_HIP_TRY(hipEventRecord(pipe_->prep_done[b], pipe_->side));
+    pipe_->resident[b] = c;
+    return 0;
+  }
+
+  StepIdentity id_;
+  PrepLayout L_;
+  int64_t K_, buf_ints_;
+  int32_t* base_;
+  hipStream_t st_;
+  Pipeline local_;          // no handle: prepare on the caller's stream, nothing survives the call
+  Pipeline* pipe_;
+  bool own_side_;
+  int64_t base_abs_ = 0;
+};
+
 int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,
                     int64_t B, int64_t n_steps, const int32_t* id_to_type, const int64_t* type_offsets,
                     int32_t n_types, const int32_t* type_ids, uint64_t seed, uint64_t global_step0,
@@ -506,60 +658,13 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
   const bool fast = train_fast_ok(B, d) && workspace_bytes >= train_ws_bytes(B, d);
   const int ring = fast ? grad_ring(B, d) : 1;
   const size_t region_floats = grad_region_bytes(B, d) / sizeof(float);
-  const PrepLayout L = prep_layout(B);
-  const int64_t K = prep_chunk_steps(B);
-  int32_t* prep_base = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + train_grad_bytes(B, d));
-  const int64_t buf_ints = (int64_t)(prep_chunk_bytes(B) / sizeof(int32_t));
-  const int direct = (L.n_sub == 1 && !hole_direct) ? 1 : 0;   // sole-slot rows updated by the producing pair
-  Pipeline* pipe = fast ? static_cast<Pipeline*>(pipe_handle) : nullptr;
-  Pipeline local;               // no handle: prepare on the caller's stream, nothing survives the call
-  int64_t base_abs = 0;
-  if (fast) {
-    if (pipe) {
-      int dev = -1;
-      GE_HIP_TRY(hipGetDevice(&dev));
-      if (dev != pipe->device) return GE_EINVAL;
-      const bool cont = pipe->live && pipe->triples == triples && pipe->id_to_type == id_to_type &&
-                        pipe->type_offsets == type_offsets && pipe->type_ids == type_ids &&
-                        pipe->workspace == workspace && pipe->T == T && pipe->B == B && pipe->N == N &&
-                        pipe->seed == seed && pipe->n_types == n_types && pipe->padded_size == padded_size &&
-                        pipe->mode == mode && pipe->d == d && pipe->direct == direct &&
-                        global_step0 == pipe->origin_gs + (uint64_t)pipe->next_abs &&
-                        norm_row(first_row, T, B) == step_row(pipe->origin_row, T, B, pipe->next_abs);
-      if (!cont) {
-        pipe->live = true;
-        pipe->triples = triples; pipe->id_to_type = id_to_type; pipe->type_offsets = type_offsets;
-        pipe->type_ids = type_ids; pipe->workspace = workspace; pipe->T = T; pipe->B = B; pipe->N = N;
-        pipe->seed = seed; pipe->n_types = n_types; pipe->padded_size = padded_size; pipe->mode = mode;
-        pipe->d = d; pipe->direct = direct;
-        pipe->origin_row = norm_row(first_row, T, B); pipe->origin_gs = global_step0; pipe->next_abs = 0;
-        pipe->resident[0] = pipe->resident[1] = -1;
-      }
-      base_abs = pipe->next_abs;
-    } else {
-      pipe = &local;
-      pipe->origin_row = norm_row(first_row, T, B); pipe->origin_gs = global_step0;
-      pipe->side = st;
-    }
-  }
-  const bool own_side = fast && pipe != &local;
-  // chunk c of the sequence -> buffer c & 1.  Before a prepare launch overwrites a buffer, the side
-  // stream waits for everything enqueued on `st` so far: that includes every step of the chunk that
-  // held the buffer before, and (first launch) earlier work that may still be writing `triples`.
-  auto ensure_chunk = [&](int64_t c) -> int {
-    const int b = (int)(c & 1);
-    if (pipe->resident[b] == c) return 0;
-    if (own_side) {
-      GE_HIP_TRY(hipEventRecord(pipe->buf_free[b], st));
-      GE_HIP_TRY(hipStreamWaitEvent(pipe->side, pipe->buf_free[b], 0));
-    }
-    int rc = prepare_launch(triples, T, pipe->origin_row, B, c * K, K, id_to_type, N, type_offsets, n_types, type_ids,
-                            seed, pipe->origin_gs, padded_size, mode, direct, prep_base + b * buf_ints, pipe->side);
-    if (rc) return rc;
-    if (own_side) GE_HIP_TRY(hipEventRecord(pipe->prep_done[b], pipe->side));
-    pipe->resident[b] = c;
-    return 0;
-  };
+  const int direct = (prep_layout(B).n_sub == 1 && !hole_direct) ? 1 : 0;   // sole-slot rows updated by the producing pair
+  const StepIdentity ident{triples, T, first_row, B, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
+                           padded_size, mode, d, direct, 0, workspace};
+  PrepCursor cur(ident, fast ? static_cast<Pipeline*>(pipe_handle) : nullptr,
+                 reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + train_grad_bytes(B, d)), st);
+  const PrepLayout& L = cur.layout();
+  if (fast) { int rc = cur.begin(); if (rc) return rc; }
   auto lr_at = [&](uint64_t gs) {
     return decay_steps > 0.f ? lr0 / (1.0f + decay_rate * ((float)gs / decay_steps)) : lr0;
   };
@@ -575,19 +680,8 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     const int32_t* step_rec = nullptr;
     if (e0 && ev_kernel == 0) (void)hipEventRecord(e0, st);
     if (fast) {
-      const int64_t abs_s = base_abs + s, chunk = abs_s / K, in_chunk = abs_s % K;
-      if (s == 0 || in_chunk == 0) {
-        rc = ensure_chunk(chunk);
-        if (rc) return rc;
-        // the next chunk is prepared on the side stream while this one trains -- also when it lies beyond
-        // this call's last step: the call that continues from there finds it done
-        if (own_side) {
-          rc = ensure_chunk(chunk + 1);
-          if (rc) return rc;
-          GE_HIP_TRY(hipStreamWaitEvent(st, pipe->prep_done[chunk & 1], 0));
-        }
-      }
-      step_rec = prep_base + (chunk & 1) * buf_ints + in_chunk * L.stride;
+      rc = cur.step(s, &step_rec);
+      if (rc) return rc;
       neg = step_rec;
     } else {
       rc = corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, gs, padded_size,
@@ -612,17 +706,110 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
   }
   if (fast) {
     // keep the caller's neg_ws meaningful: the last step's negatives
-    const int64_t la = base_abs + n_steps - 1;
-    const int32_t* last = prep_base + ((la / K) & 1) * buf_ints + (la % K) * L.stride;
+    const int32_t* last = nullptr;
+    int rc = cur.finish(n_steps, &last);
+    if (rc) return rc;
     GE_HIP_TRY(hipMemcpyAsync(neg_ws, last, sizeof(int32_t) * 3 * (size_t)B, hipMemcpyDeviceToDevice, st));
-    if (own_side) {
-      // the look-ahead launch writes into the caller's workspace after this call returns: order it before
-      // whatever the caller enqueues on `st` next (e.g. a stream-ordered free of the workspace)
-      GE_HIP_TRY(hipStreamWaitEvent(st, pipe->prep_done[((la / K) + 1) & 1], 0));
-      pipe->next_abs = base_abs + n_steps;
-    }
   }
   if (transform) { int rc = hole_spectral_launch(table, N, d, /*inverse=*/1, st); if (rc) return rc; }
+  return 0;
+}
+
+// ------------------------------------------------------------------ the --log_loss loop (holE.py:194-196, 206-220, 296)
+// Per step: M = (1+K) B triples -- the positives (label +1) and K corrupted batches (label -1, the k-th drawn
+// with Philox step key global_step * K + k) -- loss_i = log(1 + exp(-y_i s_i)) + l2 * l2_loss(table), and
+// minimize() of the SUM:   table <- table * (1 - lr M l2) - lr * sparse gradient.
+// The dense factor f_s = 1 - lr_s M l2 touches every row every step (two passes over a 960 MB table in the
+// reference's formulation).  Here the table is held as  actual = g * stored  with ONE scalar g: the dense decay
+// is g <- g f_s on the host, the kernels read stored rows times g, and the sparse update, which is in actual
+// units, is added to the stored rows divided by the NEW scale.  The table is materialised (stored *= g, one
+// pass) at the end of the call, or earlier if |g| leaves [2^-40, 2^40] or a factor is exactly 0.
+// l2_loss(table) enters only the reported loss values: it is summed (one read pass) for the steps whose loss
+// vector the caller keeps (all of them with keep_all_losses, else the last).
+size_t train_logloss_ws_bytes(int64_t B, int32_t negs, int32_t d) {
+  const size_t M = (size_t)(1 + negs) * (size_t)B;
+  const size_t region = align_up_sz(sizeof(float) * 3 * M * (size_t)d, 256);
+  size_t ring = ((size_t)64 << 20) / region + 1;
+  if (ring < 2) ring = 2;
+  if (ring > 8) ring = 8;
+  return 256 + align_up_sz(sizeof(int32_t) * 3 * M, 256) + ring * region + 2 * prep_chunk_bytes(B, negs);
+}
+
+int complex_logloss_grad_launch(const float*, int64_t, int32_t, const int32_t*, const float*, int64_t, float, float, float, const float*, float*, int32_t*, float*, hipStream_t, const int32_t*, int64_t, float, float, hipEvent_t, hipEvent_t);
+int table_sumsq_launch(const float*, int64_t, float*, hipStream_t);
+int table_scale_launch(float*, int64_t, float, hipStream_t);
+
+int train_logloss_run(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,
+                      int64_t B, int64_t n_steps, const int32_t* id_to_type, const int64_t* type_offsets,
+                      int32_t n_types, const int32_t* type_ids, uint64_t seed, uint64_t global_step0,
+                      int32_t padded_size, int32_t mode, int32_t negs, float l2, float lr0, float decay_steps,
+                      float decay_rate, float max_norm, float* loss, int keep_all_losses, int32_t* neg_ws,
+                      void* workspace, size_t workspace_bytes, void* pipe_handle, hipStream_t st) {
+  if (n_steps <= 0) return 0;
+  if (workspace_bytes < train_logloss_ws_bytes(B, negs, d)) return GE_ENOMEM;
+  const size_t M = (size_t)(1 + negs) * (size_t)B;
+  const size_t region = align_up_sz(sizeof(float) * 3 * M * (size_t)d, 256);
+  size_t ring = ((size_t)64 << 20) / region + 1;
+  if (ring < 2) ring = 2;
+  if (ring > 8) ring = 8;
+  char* w = reinterpret_cast<char*>(workspace);
+  float* sumsq = reinterpret_cast<float*>(w);
+  int32_t* gidx = reinterpret_cast<int32_t*>(w + 256);
+  char* gval0 = w + 256 + align_up_sz(sizeof(int32_t) * 3 * M, 256);
+  int32_t* prep_base = reinterpret_cast<int32_t*>(gval0 + ring * region);
+  const StepIdentity ident{triples, T, first_row, B, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
+                           padded_size, mode, d, 0, negs, workspace};
+  PrepCursor cur(ident, static_cast<Pipeline*>(pipe_handle), prep_base, st);
+  const PrepLayout& L = cur.layout();
+  int rc = cur.begin();
+  if (rc) return rc;
+  double g = 1.0;   // actual table = g * stored table
+  auto materialise = [&]() -> int {
+    if (g == 1.0) return 0;
+    int r2 = table_scale_launch(table, N * (int64_t)d, (float)g, st);
+    g = 1.0;
+    return r2;
+  };
+  for (int64_t s = 0; s < n_steps; ++s) {
+    const uint64_t gs = global_step0 + (uint64_t)s;
+    const float lr = decay_steps > 0.f ? lr0 / (1.0f + decay_rate * ((float)gs / decay_steps)) : lr0;
+    const int32_t* pos = triples + 3 * step_row(first_row, T, B, s);
+    const int32_t* step_rec = nullptr;
+    rc = cur.step(s, &step_rec);
+    if (rc) return rc;
+    const double f = 1.0 - (double)lr * (double)M * (double)l2;      // this step's dense factor
+    double g_new = g * f;
+    if (g_new == 0.0 || std::fabs(g_new) < 9.1e-13 || std::fabs(g_new) > 1.1e12) {
+      // the scalar would leave the comfortable range (or the factor is exactly 0: the reference's own defaults
+      // give f = 1 - 0.1 * 1024 * 0.1 < 0): apply the pending scale now and take this step's factor densely too
+      rc = materialise();
+      if (rc) return rc;
+      g_new = 1.0;
+    }
+    const bool want_loss = keep_all_losses || s == n_steps - 1;
+    if (want_loss) { rc = table_sumsq_launch(table, N * (int64_t)d, sumsq, st); if (rc) return rc; }
+    float* loss_s = keep_all_losses ? loss + s * (int64_t)M : loss;
+    float* gval = reinterpret_cast<float*>(gval0 + (size_t)(gs % (uint64_t)ring) * region);
+    const bool dense_now = (g_new == 1.0 && g * f != 1.0);            // this step's factor is applied by a dense pass
+    // sparse part in actual units is -lr * grad; stored rows take it divided by the scale they will carry
+    const float neg_lr_eff = (float)(-(double)lr / (dense_now ? 1.0 : g_new));
+    rc = complex_logloss_grad_launch(table, N, d, pos, nullptr, (int64_t)M, lr, max_norm, l2, want_loss ? sumsq : nullptr,
+                                     loss_s, gidx, gval, st, step_rec, B, (float)g, neg_lr_eff, nullptr, nullptr);
+    if (rc) return rc;
+    if (dense_now) {   // g == 1 here (materialised above): stored = actual; new = actual * f + sparse
+      rc = table_scale_launch(table, N * (int64_t)d, (float)f, st);
+      if (rc) return rc;
+    }
+    rc = apply_sorted_launch(table, d, L, step_rec, gidx, gval, st, nullptr, nullptr);
+    if (rc) return rc;
+    g = g_new;
+  }
+  rc = materialise();
+  if (rc) return rc;
+  const int32_t* last = nullptr;
+  rc = cur.finish(n_steps, &last);
+  if (rc) return rc;
+  GE_HIP_TRY(hipMemcpyAsync(neg_ws, last, sizeof(int32_t) * 3 * (size_t)negs * (size_t)B, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 

@@ -477,10 +477,46 @@ class Trainer:
         self.row = 0
         self.invalidate()     # the allocator may hand the new order the address of an older one
 
+    def enable_log_loss(self, negative_ratio: int = 1, l2_regularization: float = 0.1):
+        """Switch the native loop to the --log_loss objective (holE.py:194-196, 206-220): run() then enqueues
+        ge_train_steps_logloss -- negatives of all `negative_ratio` corrupted batches drawn in the prepare launch,
+        row-sorted update, the dense L2 decay carried as one scalar.  last_loss becomes [(1+K)*B]."""
+        if self.model != MODEL_COMPLEX:
+            raise NotImplementedError("--log_loss is defined for the ComplEx score (holE.py:191-196)")
+        self.K, self.l2 = int(negative_ratio), float(l2_regularization)
+        dev = self.embeddings.device
+        need = _lib.load().ge_train_logloss_workspace_bytes(self.B, self.K, self.embeddings.shape[1])
+        self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        self._neg = torch.empty(self.K, self.B, 3, dtype=torch.int32, device=dev)
+        self.last_loss = torch.zeros((1 + self.K) * self.B, dtype=torch.float32, device=dev)
+        self.invalidate()
+        return self
+
+    def _run_logloss(self, n_steps: int, keep_losses: bool):
+        emb, T = self.embeddings, self.triples.shape[0]
+        M = (1 + self.K) * self.B
+        loss = torch.empty(n_steps * M, dtype=torch.float32, device=emb.device) if keep_losses else self.last_loss
+        _lib.call("ge_train_steps_logloss", emb.data_ptr(), emb.shape[0], emb.shape[1], self.triples.data_ptr(), T,
+                  self.row, self.B, n_steps, self.tt.id_to_type.data_ptr(), self.tt.type_offsets.data_ptr(),
+                  self.tt.n_types, self.tt.type_ids.data_ptr(), self.seed & (2**64 - 1), self.global_step,
+                  self.tt.padded_size, self.mode, self.K, self.l2, self.lr0, self.decay_steps, self.decay_rate,
+                  self.max_norm, loss.data_ptr(), int(keep_losses), self._neg.data_ptr(), self._ws.data_ptr(),
+                  self._ws.numel(), self._pipe, _stream())
+        row = self.row % T
+        for _ in range(n_steps):
+            if row + self.B > T:
+                row = 0
+            row += self.B
+        self.row = row
+        self.global_step += n_steps
+        return loss.view(n_steps, M) if keep_losses else loss
+
     def run(self, n_steps: int, *, keep_losses: bool = False, events=None, ev_kernel: int = 2):
         """Enqueue n_steps training steps on the current stream; returns the loss tensor
         ([n_steps,B] if keep_losses else the last step's [B])."""
         import ctypes as C
+        if getattr(self, "K", 0):
+            return self._run_logloss(n_steps, keep_losses)
         emb, T = self.embeddings, self.triples.shape[0]
         loss = (torch.empty(n_steps * self.B, dtype=torch.float32, device=emb.device)
                 if keep_losses else self.last_loss)

@@ -10,7 +10,8 @@ negatives is printed (holE.py:351-354) and the table is saved when it improves o
 which starts at 2.0 (holE.py:329, 357-360); the output directory must not exist unless
 --resume_checkpoint (holE.py:254-255).  TF mechanics (queues, sessions, summaries, the V2
 checkpoint bundle) are not: the table is saved as `model.ckpt.pt` (embeddings + global_step).
-Between validation ticks the steps are enqueued natively by ge_train_steps -- no Python per step.
+Between validation ticks the steps are enqueued natively by ge_train_steps (hinge) or
+ge_train_steps_logloss (--log_loss) -- no Python per step.
 Extras: --model hole (README.md:42 score), --seed, --max_steps.
 """
 from __future__ import annotations
@@ -111,27 +112,19 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
     valid = None
     if data.validation_triples is not None and len(data.validation_triples) >= FLAGS.batch_size:
         valid = torch.as_tensor(data.validation_triples).cuda()
-    logloss = H.LogLossSGD(embeddings, FLAGS.l2_regularization) if FLAGS.log_loss else None
     K = max(1, FLAGS.negative_ratio)
+    if FLAGS.log_loss:
+        # --log_loss (holE.py:206-220): the same native loop, K corrupted batches per step drawn in the prepare launch
+        trainer.enable_log_loss(K, FLAGS.l2_regularization)
 
-    def logloss_steps(n, lr_zero=False, batch_override=None):
-        """--log_loss branch (holE.py:206-220): K corrupted batches per step, label -1; Python per step."""
-        out = None
-        for _ in range(n):
-            if batch_override is None:
-                if trainer.row + FLAGS.batch_size > trainer.triples.shape[0]:
-                    trainer.row = 0
-                pos = trainer.triples[trainer.row:trainer.row + FLAGS.batch_size]
-            else:
-                pos = batch_override
-            gs = trainer.global_step
-            negs = [H.corrupt_batch(tt, data.relation_count, pos, seed=FLAGS.seed, step=gs * K + i) for i in range(K)]
-            out = logloss.step(pos, negs, 0.0 if lr_zero else trainer.learning_rate(gs))
-            if batch_override is None:
-                trainer.row += FLAGS.batch_size
-                trainer.global_step += 1
-                trainer.last_loss = out[:, 0]
-        return out
+    def logloss_validation(batch):
+        """mean of the loss vector for one validation batch with fresh negatives (the table is only read)."""
+        gs = trainer.global_step
+        vals = [H.evaluate_triples(batch, embeddings, 1, l2_regularization=FLAGS.l2_regularization)]
+        for i in range(K):
+            neg = H.corrupt_batch(tt, data.relation_count, batch, seed=FLAGS.seed ^ 0x5EED, step=gs * K + i)
+            vals.append(H.evaluate_triples(neg, embeddings, -1, l2_regularization=FLAGS.l2_regularization))
+        return float(torch.cat(vals, 0).mean())
 
     tick = max(1, batch_count // 16)          # guard for the ZeroDivisionError of holE.py:351
     pocket_loss = 2.
@@ -145,8 +138,8 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
         while batch < batch_count and not done:
             if batch % tick == 0 and valid is not None:
                 sel = torch.randint(0, valid.shape[0], (FLAGS.batch_size,), device='cuda', generator=gen)
-                if logloss is not None:   # mean of the loss vector at lr = 0 (table untouched)
-                    vlm = float(logloss_steps(1, lr_zero=True, batch_override=valid[sel].contiguous()).mean())
+                if FLAGS.log_loss:
+                    vlm = logloss_validation(valid[sel].contiguous())
                 else:
                     vlm = float(H.evaluate_batch(valid[sel], embeddings, tt, None, data.relation_count,
                                                  margin=FLAGS.margin, model=eval_model, seed=FLAGS.seed ^ 0x5EED,
@@ -163,10 +156,7 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
             if FLAGS.max_steps:
                 n = min(n, FLAGS.max_steps - (trainer.global_step - global_step))
             if n > 0:
-                if logloss is not None:
-                    logloss_steps(n)
-                else:
-                    trainer.run(n)
+                trainer.run(n)
             batch += max(n, 0)
             if FLAGS.max_steps and trainer.global_step - global_step >= FLAGS.max_steps:
                 done = True

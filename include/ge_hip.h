@@ -253,6 +253,26 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
                    int model, float* loss, int keep_all_losses, int32_t* neg_ws, void* workspace,
                    size_t workspace_bytes, void** ev_pairs, int ev_kernel, void* pipeline, void* stream);
 
+/* --- the same loop for the --log_loss objective (holE.py:194-196, 206-220, minimised as holE.py:296), ComplEx:
+ * per step the M = (1 + negative_ratio) * B triples are the positives (label +1) followed by negative_ratio
+ * corrupted batches (label -1; the k-th is ge_corrupt_batch with step = (global_step0 + s) * negative_ratio + k),
+ * loss_i = log(1 + exp(-y_i s_i)) + l2 * sum(table^2) / 2, and table <- table * (1 - lr M l2) - lr * sparse gradient.
+ * Negatives and the row-sorted slot index (slot = 3 * triple + {h, t, r}) are prepared ahead as in
+ * ge_train_steps; the dense decay is carried as one scalar between steps (rows are read scaled, the sparse
+ * update is divided by the new scale) and the table is materialised once, before the call returns -- instead of
+ * two passes over the whole table per step; sum(table^2) is formed only for the steps whose loss is kept.
+ * loss: [n_steps * M] with keep_all_losses, else [M] (last step), in the reference's concat order.
+ * neg_ws: [negative_ratio, B, 3] int32 (last step's negatives on return).  workspace >=
+ * ge_train_logloss_workspace_bytes(B, negative_ratio, d), 256-B aligned.  pipeline: as for ge_train_steps
+ * (a handle used for the hinge loop restarts when it meets this one and vice versa). */
+size_t ge_train_logloss_workspace_bytes(int64_t B, int32_t negative_ratio, int32_t d);
+int ge_train_steps_logloss(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,
+                           int64_t B, int64_t n_steps, const int32_t* id_to_type, const int64_t* type_offsets,
+                           int32_t n_types, const int32_t* type_ids, uint64_t seed, uint64_t global_step0,
+                           int32_t padded_size, int32_t mode, int32_t negative_ratio, float l2, float lr0,
+                           float decay_steps, float decay_rate, float max_norm, float* loss, int keep_all_losses,
+                           int32_t* neg_ws, void* workspace, size_t workspace_bytes, void* pipeline, void* stream);
+
 /* The prepare launch on its own: the records of n_steps consecutive steps, as ge_train_steps builds
  * them, into `out` (>= n_steps * layout[0] int32 words).  ge_train_prepared_layout fills out8 =
  * {words per step record, sub-batches per step, pairs per sub-batch S, offset of slot_item[6B],

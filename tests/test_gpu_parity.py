@@ -884,3 +884,65 @@ def test_init_embeddings_is_the_reference_initializer(H):
     assert abs(t.std().item() / sigma - 0.87963) < 3e-3
     assert (t.abs() > 1.9 * sigma).float().mean().item() > 1e-3             # the tail up to the cut is populated
     assert torch.equal(t, H.init_embeddings(n, d, seed=5)) and not torch.equal(t, H.init_embeddings(n, d, seed=6))
+
+
+@pytest.mark.parametrize("B,K,d,l2", [(512, 1, 128, 1e-4), (300, 3, 50, 3e-5), (2048, 2, 200, 2e-5), (512, 1, 64, 0.0)])
+def test_native_logloss_loop_matches_oracle_over_twenty_dependent_steps(H, B, K, d, l2):
+    """ge_train_steps_logloss (negatives of all K corrupted batches from the prepare launch, row-sorted update, the
+    dense L2 decay carried as one scalar and materialised at the end) against the fp64 oracle replaying
+    holE.py:206-220 + 296 step by step: every step's loss vector and the final table.  (2048, 2): M = 6,144
+    triples = two sort sub-batches, update through atomics.)"""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    steps, T = 20, 6 * B + 31
+    tri = D.synthetic_fb15k_triples(fb, n_triples=T, seed=19)
+    table = O.init_table(fb.entity_count, d, seed=9)
+    table[::5] *= 9.0
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    emb = dev(table).clone()
+    tr = H.Trainer(emb, dev(tri), tt, B, learning_rate=0.05, decay_steps=40.0, decay_rate=0.5, seed=77)
+    tr.enable_log_loss(K, l2)
+    tr.global_step = 5
+    losses = torch.cat([tr.run(7, keep_losses=True), tr.run(13, keep_losses=True)], 0).cpu().numpy()   # two calls: the scalar restarts at 1
+    assert losses.shape == (steps, (1 + K) * B)
+    t64 = table.astype(np.float64)
+    row = 0
+    for s in range(steps):
+        if row + B > T:
+            row = 0
+        pos = tri[row:row + B]
+        gs = 5 + s
+        negs = np.stack([CO.corrupt_batch(pos, id_to_type, offsets, ids, 77, gs * K + k, 1024, 0) for k in range(K)])
+        lr = np.float32(0.05) / (np.float32(1.0) + np.float32(0.5) * (np.float32(gs) / np.float32(40.0)))
+        t64, oloss = O.logloss_step(t64, pos, negs, float(lr), l2)
+        assert np.abs(losses[s] - oloss).max() < 3e-5 * max(1.0, np.abs(oloss).max()), s
+        row += B
+    assert np.abs(emb.cpu().numpy() - t64).max() < 2e-5
+    assert np.array_equal(tr._neg.cpu().numpy(), negs)
+    tr.close()
+
+
+def test_native_logloss_loop_survives_the_reference_default_l2(H):
+    """holE.py's own defaults (lr 0.1, batch 512, l2 0.1) make the dense factor 1 - lr*M*l2 = -9.24: the table
+    changes sign and grows ~9x per step.  The carried scalar is re-materialised when it leaves its range; the
+    loop must follow the oracle as long as fp32 holds (6 steps: ~6e5 growth)."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    B, K, d, steps = 512, 1, 64, 6
+    tri = D.synthetic_fb15k_triples(fb, n_triples=8 * B, seed=23)
+    table = O.init_table(fb.entity_count, d, seed=10)
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    emb = dev(table).clone()
+    tr = H.Trainer(emb, dev(tri), tt, B, learning_rate=0.1, seed=3).enable_log_loss(K, 0.1)
+    tr.run(steps)
+    t64 = table.astype(np.float64)
+    for s in range(steps):
+        pos = tri[s * B:(s + 1) * B]
+        negs = np.stack([CO.corrupt_batch(pos, id_to_type, offsets, ids, 3, s * K + k, 1024, 0) for k in range(K)])
+        t64, _ = O.logloss_step(t64, pos, negs, 0.1, 0.1)
+    scale = np.abs(t64).max()
+    assert scale > 1e3                                                   # it did blow up, as the reference would
+    assert np.abs(emb.cpu().numpy() - t64).max() < 1e-4 * scale
+    tr.close()
