@@ -70,16 +70,30 @@ __device__ __forceinline__ void rank_mma(const float* __restrict__ ap, const flo
   }
 }
 
+// Chunk `ch` (32 reals) of candidate row `cid` into registers: thread t stages row t>>1, half t&1.
+__device__ __forceinline__ void rank_fetch(const float* __restrict__ table, int64_t N, int d, int32_t cid, int ch,
+                                           float4 (&r)[4]) {
+  const int half = threadIdx.x & 1;
+  const bool bad = cid < 0 || cid >= N;
+  const float* crow = table + (int64_t)(bad ? 0 : cid) * d;
+  const int c0 = ch * kChunk + half * 16;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int c = c0 + 4 * v;
+    r[v] = (!bad && c + 3 < d) ? *reinterpret_cast<const float4*>(crow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // One 128 x 128 tile: acc = Q . T^T for the candidate rows `cid` (this thread stages row t>>1, half t&1),
-// candidate clip scales to lds.sB.  Identical instruction sequence for every tile, diagonal tile included.
+// candidate clip scales to lds.sB.  `r` holds chunk 0 of the row on entry (the caller fetched it -- under the
+// previous tile's epilogue).  Identical instruction sequence for every tile, diagonal tile included.
 __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64_t N, int d, int lda,
-                                          int32_t cid, float max_norm, const RankLds& lds,
+                                          int32_t cid, float max_norm, const RankLds& lds, float4 (&r)[4],
                                           f32x16 (&acc)[2][2]) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int srow = t >> 1, half = t & 1;
   const int li = lane & 31, lh = lane >> 5;
   const bool bad = cid < 0 || cid >= N;
-  const float* crow = table + (int64_t)(bad ? 0 : cid) * d;
   const int n_chunks = (d + kChunk - 1) / kChunk;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -88,15 +102,6 @@ __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
   float ss = 0.f;
-  float4 r[4];
-  auto fetch = [&](int ch) {
-    const int c0 = ch * kChunk + half * 16;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int c = c0 + 4 * v;
-      r[v] = (!bad && c + 3 < d) ? *reinterpret_cast<const float4*>(crow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
   auto stash = [&](int buf) {
     float* dst = lds.Bs + (buf * kRB + srow) * kLdb + half * 16;
 #pragma unroll
@@ -105,18 +110,16 @@ __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64
       ss += r[v].x * r[v].x + r[v].y * r[v].y + r[v].z * r[v].z + r[v].w * r[v].w;
     }
   };
-  fetch(0);
   stash(0);
   __syncthreads();
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < n_chunks) fetch(ch + 1);                       // global loads fly under the MFMAs
+    if (ch + 1 < n_chunks) rank_fetch(table, N, d, cid, ch + 1, r);   // global loads fly under the MFMAs
     const int kmax = min(kChunk, d - ch * kChunk);               // 32, or the 8-float tail at d = 200
     const float* ap = lds.A + (wm * 64 + li) * lda + ch * kChunk + lh;
     const float* bp = lds.Bs + (buf * kRB + wn * 64 + li) * kLdb + lh;
-    if (kmax == kChunk) {                                        // two halves: 64 operand registers in flight
-      rank_mma<8>(ap, bp, lda, acc);
-      rank_mma<8>(ap + 16, bp + 16, lda, acc);
+    if (kmax == kChunk) {                                        // all 64 operand reads of the chunk, then its 64 MFMAs
+      rank_mma<16>(ap, bp, lda, acc);
     } else {                                                     // the tail chunk: 8, 16 or 24 reals
       for (int kk = 0; kk < kmax; kk += 8) rank_mma<4>(ap + kk, bp + kk, lda, acc);
     }
@@ -204,8 +207,10 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
   f32x16 acc[2][2];
   // ---- the true candidates' losses: a tile whose candidate rows are this block's 128 true entities
   float et[2][16];     // E of the true candidate of each of this lane's 32 accumulator rows, for the whole sweep
+  float4 rbuf[4];      // chunk 0 of the NEXT tile's candidate row, requested before the current tile's epilogue
   {
-    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, acc);
+    rank_fetch(table, N, d, lds.tI[srow], 0, rbuf);
+    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, rbuf, acc);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -227,11 +232,17 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
   int raw_reg = 0;
 
   // ---- the sweep over this split's candidate tiles
+  auto cand_of = [&](int ct) -> int32_t {
+    const int64_t c = (int64_t)ct * kRB + srow;
+    return (ct < n_ct && c < K) ? cand[c] : -1;
+  };
+  int32_t cid = cand_of(blockIdx.x);
+  rank_fetch(table, N, d, cid, 0, rbuf);
   for (int ct = blockIdx.x; ct < n_ct; ct += gridDim.x) {
     const int64_t n0 = (int64_t)ct * kRB;
-    const int64_t c = n0 + srow;
-    const int32_t cid = c < K ? cand[c] : -1;
-    rank_tile(table, N, d, lda, cid, max_norm, lds, acc);
+    rank_tile(table, N, d, lda, cid, max_norm, lds, rbuf, acc);
+    cid = cand_of(ct + gridDim.x);
+    rank_fetch(table, N, d, cid, 0, rbuf);                       // lands while the epilogue below runs
     // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // A candidate beyond K or with a bad id has a NaN clip scale, a row beyond B a NaN Q: every comparison false.
 #pragma unroll

@@ -87,3 +87,37 @@ def test_segment_items_cuts_long_segments():
     assert it.begin.tolist() == [0, 1, 33, 65, 71, 74, 106, 138]
     assert it.target.tolist() == [7, -9, -9, -9, 0, 1, -3, -3]  # split rows are encoded as ~row
     assert it.split_rows.tolist() == [8, 2]
+
+
+def test_known_index_cells_match_brute_force():
+    """evaluate.KnownIndex (device-agnostic tensor code): the per-(128 x 128)-tile lists of known-true cells the
+    fused ranking kernel takes, against a brute-force enumeration; duplicates in the known triples count once."""
+    import torch
+    rng = np.random.default_rng(7)
+    N, R, B, K = 900, 6, 300, 700
+    known = np.stack([rng.integers(R, N, 4000), rng.integers(R, N, 4000), rng.integers(0, R, 4000)], 1)
+    known = np.concatenate([known, known[:500]])                    # duplicates
+    cand = np.sort(rng.permutation(np.arange(R, N))[:K])
+    pos_of = torch.full((N,), -1, dtype=torch.int64)
+    pos_of[torch.as_tensor(cand)] = torch.arange(K)
+    test = known[rng.integers(0, len(known), B)]
+    for side in ("tail", "head"):
+        fc, oc = (0, 1) if side == "tail" else (1, 0)
+        idx = E.KnownIndex(known, N, side, torch.device("cpu"))
+        off, rc = idx.cells(torch.as_tensor(test[:, fc]), torch.as_tensor(test[:, 2]), pos_of, K)
+        n_ct = (K + 127) // 128
+        got = set()
+        off = off.numpy()
+        for tile in range(len(off) - 1):
+            for v in rc.numpy()[off[tile]:off[tile + 1]].astype(np.int64):
+                got.add(((tile // n_ct) * 128 + v // 128, (tile % n_ct) * 128 + v % 128))
+        exp = set()
+        kn = {(int(a[fc]), int(a[2]), int(a[oc])) for a in known}
+        by = {}
+        for f, r, o in kn:
+            by.setdefault((f, r), []).append(o)
+        for i, t in enumerate(test):
+            for o in by.get((int(t[fc]), int(t[2])), []):
+                if pos_of[o] >= 0:
+                    exp.add((i, int(pos_of[o])))
+        assert got == exp and int(off[-1]) == len(exp)
