@@ -80,20 +80,26 @@ __device__ __forceinline__ void rank_fetch(const float* __restrict__ table, int6
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int c = c0 + 4 * v;
-    r[v] = (!bad && c + 3 < d) ? *reinterpret_cast<const float4*>(crow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[v] = *reinterpret_cast<const float4*>(crow + min(c, d - 4));   // clamped, never predicated; zeroed when stored
   }
 }
 
 // One 128 x 128 tile: acc = Q . T^T for the candidate rows `cid` (this thread stages row t>>1, half t&1),
-// candidate clip scales to lds.sB.  `r` holds chunk 0 of the row on entry (the caller fetched it -- under the
-// previous tile's epilogue).  Identical instruction sequence for every tile, diagonal tile included.
+// candidate clip scales to lds.sB.  rA / rB hold chunks 0 and 1 of the row on entry (the caller requested them
+// under the previous tile's epilogue).  Identical instruction sequence for every tile, diagonal tile included.
+//
+// A chunk iteration is ONE instruction stream per wave (one wave per SIMD): everything that is not an MFMA is
+// cut into slices of a few instructions and placed BETWEEN the MFMAs, where it issues in the shadow of the
+// 64-cycle matrix instruction before it: iteration ch stores chunk ch+1 (registers, requested an iteration
+// ago) to the free LDS buffer in 8 slices, then requests chunk ch+2 in 4 slices.  sched_barriers pin the order.
 __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64_t N, int d, int lda,
-                                          int32_t cid, float max_norm, const RankLds& lds, float4 (&r)[4],
-                                          f32x16 (&acc)[2][2]) {
+                                          int32_t cid, float max_norm, const RankLds& lds, float4 (&rA)[4],
+                                          float4 (&rB)[4], f32x16 (&acc)[2][2]) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int srow = t >> 1, half = t & 1;
   const int li = lane & 31, lh = lane >> 5;
   const bool bad = cid < 0 || cid >= N;
+  const float* crow = table + (int64_t)(bad ? 0 : cid) * d;
   const int n_chunks = (d + kChunk - 1) / kChunk;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -102,28 +108,77 @@ __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
   float ss = 0.f;
-  auto stash = [&](int buf) {
-    float* dst = lds.Bs + (buf * kRB + srow) * kLdb + half * 16;
+  {  // chunk 0 -> buffer 0
+    float* dst = lds.Bs + srow * kLdb + half * 16;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      dst[4 * v] = r[v].x; dst[4 * v + 1] = r[v].y; dst[4 * v + 2] = r[v].z; dst[4 * v + 3] = r[v].w;
-      ss += r[v].x * r[v].x + r[v].y * r[v].y + r[v].z * r[v].z + r[v].w * r[v].w;
+      const bool ok = !bad && half * 16 + 4 * v + 3 < d;
+      const float x = ok ? rA[v].x : 0.f, y = ok ? rA[v].y : 0.f, z = ok ? rA[v].z : 0.f, w2 = ok ? rA[v].w : 0.f;
+      dst[4 * v] = x; dst[4 * v + 1] = y; dst[4 * v + 2] = z; dst[4 * v + 3] = w2;
+      ss += x * x + y * y + z * z + w2 * w2;
     }
-  };
-  stash(0);
+  }
   __syncthreads();
-  for (int ch = 0; ch < n_chunks; ++ch) {
+  // body(ch, rs, rf): rs holds chunk ch+1, rf is free and receives chunk ch+2
+  auto body = [&](int ch, float4 (&rs)[4], float4 (&rf)[4]) {
     const int buf = ch & 1;
-    if (ch + 1 < n_chunks) rank_fetch(table, N, d, cid, ch + 1, r);   // global loads fly under the MFMAs
-    const int kmax = min(kChunk, d - ch * kChunk);               // 32, or the 8-float tail at d = 200
     const float* ap = lds.A + (wm * 64 + li) * lda + ch * kChunk + lh;
     const float* bp = lds.Bs + (buf * kRB + wn * 64 + li) * kLdb + lh;
-    if (kmax == kChunk) {                                        // all 64 operand reads of the chunk, then its 64 MFMAs
-      rank_mma<16>(ap, bp, lda, acc);
-    } else {                                                     // the tail chunk: 8, 16 or 24 reals
-      for (int kk = 0; kk < kmax; kk += 8) rank_mma<4>(ap + kk, bp + kk, lda, acc);
+    float* dst = lds.Bs + ((buf ^ 1) * kRB + srow) * kLdb + half * 16;
+    const int c2 = (ch + 2) * kChunk + half * 16;
+    float a0[16], a1[16], b0[16], b1[16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      a0[s2] = ap[2 * s2]; a1[s2] = ap[32 * lda + 2 * s2];
+      b0[s2] = bp[2 * s2]; b1[s2] = bp[32 * kLdb + 2 * s2];
     }
-    if (ch + 1 < n_chunks) stash(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // No control flow in here: a branch makes the waitcnt pass serialise the requests (vmcnt(0) before each).
+    // Requests past the row's end are clamped to its last 16 bytes and zeroed when they are stored.
+    auto piece = [&](int pc) {
+      if (pc < 4) {                                   // one 16-byte request of chunk ch+2
+        rf[pc] = *reinterpret_cast<const float4*>(crow + min(c2 + 4 * pc, d - 4));
+      } else if (pc >= 8 && pc < 40 && (pc & 3) == 0) {   // half a float4 of chunk ch+1 to LDS, its squares to the norm
+        const int i = (pc - 8) >> 2, v = i >> 1;
+        const bool ok = !bad && c2 - kChunk + 4 * v + 3 < d;
+        if (i & 1) {
+          const float z = ok ? rs[v].z : 0.f, w2 = ok ? rs[v].w : 0.f;
+          dst[4 * v + 2] = z; dst[4 * v + 3] = w2; ss += z * z + w2 * w2;
+        } else {
+          const float x = ok ? rs[v].x : 0.f, y = ok ? rs[v].y : 0.f;
+          dst[4 * v] = x; dst[4 * v + 1] = y; ss += x * x + y * y;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s2], b0[s2], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(4 * s2);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s2], b1[s2], acc[0][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(4 * s2 + 1);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s2], b0[s2], acc[1][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(4 * s2 + 2);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s2], b1[s2], acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(4 * s2 + 3);
+    }
+    __syncthreads();
+  };
+  const int n_full = d / kChunk;
+  int ch = 0;
+  for (; ch + 1 < n_full; ch += 2) {      // register sets swap roles every iteration
+    body(ch, rB, rA);
+    body(ch + 1, rA, rB);
+  }
+  if (ch < n_full) { body(ch, rB, rA); ++ch; }
+  if (n_full < n_chunks) {                // the 8/16/24-real tail chunk (already in LDS)
+    const float* ap = lds.A + (wm * 64 + li) * lda + n_full * kChunk + lh;
+    const float* bp = lds.Bs + ((n_full & 1) * kRB + wn * 64 + li) * kLdb + lh;
+    for (int kk = 0; kk < d - n_full * kChunk; kk += 8) rank_mma<4>(ap + kk, bp + kk, lda, acc);
     __syncthreads();
   }
   ss += __shfl_xor(ss, 1, kWave);
@@ -207,10 +262,11 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
   f32x16 acc[2][2];
   // ---- the true candidates' losses: a tile whose candidate rows are this block's 128 true entities
   float et[2][16];     // E of the true candidate of each of this lane's 32 accumulator rows, for the whole sweep
-  float4 rbuf[4];      // chunk 0 of the NEXT tile's candidate row, requested before the current tile's epilogue
+  float4 rA[4], rB[4];  // chunks 0 and 1 of the NEXT tile's candidate row, requested before the current tile's epilogue
   {
-    rank_fetch(table, N, d, lds.tI[srow], 0, rbuf);
-    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, rbuf, acc);
+    rank_fetch(table, N, d, lds.tI[srow], 0, rA);
+    rank_fetch(table, N, d, lds.tI[srow], 1, rB);
+    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, rA, rB, acc);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -237,12 +293,14 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     return (ct < n_ct && c < K) ? cand[c] : -1;
   };
   int32_t cid = cand_of(blockIdx.x);
-  rank_fetch(table, N, d, cid, 0, rbuf);
+  rank_fetch(table, N, d, cid, 0, rA);
+  rank_fetch(table, N, d, cid, 1, rB);
   for (int ct = blockIdx.x; ct < n_ct; ct += gridDim.x) {
     const int64_t n0 = (int64_t)ct * kRB;
-    rank_tile(table, N, d, lda, cid, max_norm, lds, rbuf, acc);
+    rank_tile(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);
     cid = cand_of(ct + gridDim.x);
-    rank_fetch(table, N, d, cid, 0, rbuf);                       // lands while the epilogue below runs
+    rank_fetch(table, N, d, cid, 0, rA);                         // land while the epilogue below runs
+    rank_fetch(table, N, d, cid, 1, rB);
     // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // A candidate beyond K or with a bad id has a NaN clip scale, a row beyond B a NaN Q: every comparison false.
 #pragma unroll
