@@ -20,22 +20,12 @@
 // Epilogue per tile: sigmoid, compare, one ballot per accumulator register -> a 128 x 128 bit mask in
 // LDS; a thread per row pop-counts it (raw), and the tile's (row, col) list of known-true candidates,
 // prepared by the host, is looked up in the same mask (filtered).
-#include "ge_common.h"
+#include "ge_rank_dev.h"
 
 namespace ge {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr int kRB = 128;          // rows per workgroup, columns per tile
 constexpr int kChunk = 32;        // reals per staged B chunk
 constexpr int kLdb = kChunk + 1;  // odd LDS stride
-
-// sigmoid for the ranking epilogue: 4 VALU instructions (v_exp_f32, v_rcp_f32; ~2 ulp), used for EVERY loss this
-// kernel forms -- candidates and true entities alike -- so comparisons are self-consistent; within 1e-6 of
-// sigmoidf_dev, well inside the 1e-5 score bar.
-__device__ __forceinline__ float rank_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
-}
 
 struct RankLds {
   float* A;        // [kRB][lda]
@@ -359,6 +349,11 @@ int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int3
   if (d > rank_max_dim()) return GE_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
   if (B == 0 || K == 0) return 0;
+  {  // embedding_dim a multiple of 40, 32 or 24: the software-pipelined kernel (ge_rank_pipe.hip)
+    const int rc = rank_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,
+                                    raw_cnt, skip_cnt, true_loss, scores_out, st);
+    if (rc != GE_ENOTSUP) return rc;
+  }
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
   if (n_rb > 65535) return GE_ENOTSUP;
   // column splits: enough workgroups for ~4 waves of the 256 CUs, never more than column tiles

@@ -9,10 +9,10 @@ g = torch.Generator(device="cuda").manual_seed(0)
 hr = torch.stack([torch.randint(R, N, (B,), device="cuda", generator=g), torch.randint(0, R, (B,), device="cuda", generator=g)], 1).int()
 tid = torch.randint(R, N, (B,), device="cuda", generator=g).int()
 c = torch.arange(R, N, dtype=torch.int32, device="cuda")
-for d in (8, 104, 200):
+for d in (40, 120, 200):
     emb = torch.randn(N, d, device="cuda", generator=g) * 0.1
     H.rank_candidates(emb, hr, tid, c)
     out = H.rank_candidates(emb, hr, tid, c, return_true_loss=True)
     torch.cuda.synchronize()
-    v = out[2][:5].cpu().numpy()
-    print(f"d={d} setup {v[0]:.0f} diag {v[1]:.0f} tiles {v[2]:.0f} ({v[2]/v[4]:.0f}/tile) epi {v[3]:.0f} ({v[3]/v[4]:.0f}/tile) n_tiles {v[4]:.0f}  [ticks]")
+    v = out[2][:7].cpu().numpy()
+    print(f"d={d} setup {v[0]:.0f} diag {v[1]:.0f} ({v[6]:.0f} segs) tiles {v[2]:.0f} ({v[2]/v[4]:.0f}/tile) epi {v[3]:.0f} ({v[3]/v[4]:.0f}/tile) epi2 {v[5]/v[4]:.0f}/tile n_tiles {v[4]:.0f}  [ticks]")
