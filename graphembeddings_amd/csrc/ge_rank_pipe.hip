@@ -36,6 +36,8 @@ struct Cfg {
   static_assert(CW % 8 == 0 && kNG >= 2 && 4 * (kNG - 1) >= 2 * kNV, "chunk width");
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct Ops { float a0[4], a1[4], b0[4], b1[4]; };   // 4 k-pairs of this wave's 64 x 64 block: 2 A and 2 B fragments
 
 struct PipeLds {
@@ -102,11 +104,12 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-  float ss = 0.f;
+  f2 ss2 = {0.f, 0.f};                                              // the row's sum of squares, one v_pk_fma_f32 per 2 reals
 #pragma unroll
   for (int v = 0; v < NV; ++v) {                                    // chunk 0 -> buffer 0
     st0[4 * v] = rA[v].x; st0[4 * v + 1] = rA[v].y; st0[4 * v + 2] = rA[v].z; st0[4 * v + 3] = rA[v].w;
-    ss += rA[v].x * rA[v].x + rA[v].y * rA[v].y + rA[v].z * rA[v].z + rA[v].w * rA[v].w;
+    ss2 = __builtin_elementwise_fma(f2{rA[v].x, rA[v].y}, f2{rA[v].x, rA[v].y}, ss2);
+    ss2 = __builtin_elementwise_fma(f2{rA[v].z, rA[v].w}, f2{rA[v].z, rA[v].w}, ss2);
   }
   __syncthreads();
   Ops ops[2];
@@ -144,8 +147,13 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
         } else if (j < 12) {                                        // half a float4 of chunk q+1 to LDS
           const int sp = 4 * g + (j - 8), v = sp >> 1;
           if (!LAST && g < NG - 1 && sp < 2 * NV) {
-            if (sp & 1) { dst[4 * v + 2] = rs[v].z; dst[4 * v + 3] = rs[v].w; ss += rs[v].z * rs[v].z + rs[v].w * rs[v].w; }
-            else { dst[4 * v] = rs[v].x; dst[4 * v + 1] = rs[v].y; ss += rs[v].x * rs[v].x + rs[v].y * rs[v].y; }
+            if (sp & 1) {
+              dst[4 * v + 2] = rs[v].z; dst[4 * v + 3] = rs[v].w;
+              ss2 = __builtin_elementwise_fma(f2{rs[v].z, rs[v].w}, f2{rs[v].z, rs[v].w}, ss2);
+            } else {
+              dst[4 * v] = rs[v].x; dst[4 * v + 1] = rs[v].y;
+              ss2 = __builtin_elementwise_fma(f2{rs[v].x, rs[v].y}, f2{rs[v].x, rs[v].y}, ss2);
+            }
           }
         } else {                                                    // one 16-byte request of chunk q+2
           const int fp = 4 * g + (j - 12);
@@ -168,6 +176,7 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
   } else {
     chunk(B0{}, std::true_type{}, q, rB, rA);
   }
+  float ss = ss2.x + ss2.y;
   ss += __shfl_xor(ss, 1, kWave);
   if (half == 0) {
     float inv;
@@ -189,6 +198,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int LANE>
 __device__ __forceinline__ void set_lane(int& m, unsigned v) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(v), "n"(LANE));
+}
+
+// m = 2 * m + (this lane's bit of the wave mask): one v_addc_co_u32 with the mask as carry-in
+__device__ __forceinline__ void shift_in(unsigned& m, unsigned long long mask) {
+  unsigned long long carry_out;
+  asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(m), "=s"(carry_out) : "s"(mask));
 }
 
 // The exact comparison for one accumulator register of both column halves: fp32 sigmoid of the scaled score, ties
@@ -330,15 +345,26 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       const int64_t c = (int64_t)ct * kRB + srow;
       return (ct < ct1 && c < K) ? cand[c] : -1;
     };
-    int32_t cid = cand_of(ct0);
+    auto known_of = [&](int ct, int32_t& k0, int32_t& k1) {
+      k0 = k1 = 0;
+      if (known_off && ct < ct1) {
+        const int64_t tile = (int64_t)rb * n_ct + ct;
+        k0 = known_off[tile]; k1 = known_off[tile + 1];
+      }
+    };
+    // candidate ids and known-cell ranges are requested one tile ahead of their use: nothing ever waits on them
+    int32_t cid = cand_of(ct0), cid_next = cand_of(ct0 + 1), kn0, kn1, kn0_next, kn1_next;
+    known_of(ct0, kn0_next, kn1_next);
     pipe_fetch<CW>(table, N, d, cid, 0, rA);
     pipe_fetch<CW>(table, N, d, cid, 1, rB);
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
       pipe_tile<CW>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);
-      cid = cand_of(ct + 1);
+      cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
       pipe_fetch<CW>(table, N, d, cid, 0, rA);                   // land while the epilogue below runs
       pipe_fetch<CW>(table, N, d, cid, 1, rB);
+      cid_next = cand_of(ct + 2);
+      known_of(ct + 1, kn0_next, kn1_next);
       // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
       // A candidate beyond K or with a bad id has a NaN clip scale, a row beyond B a NaN bracket: no bit is set.
       const int cl0 = wn * 64 + li, cl1 = cl0 + 32;
@@ -346,40 +372,54 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
         int M0 = 0, M1 = 0;                                      // lane r: the 32 column bits of row r of the 32 x 32 block
-        unsigned amb = 0;                                        // bit q: register q has a score inside a bracket
-        static_for<0, 16>([&](auto qc) {
-          constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
-          const float2 br = lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh];
-          const float x0 = acc[tm][0][q] * sb0, x1 = acc[tm][1][q] * sb1;
-          const unsigned long long lt0 = __ballot(x0 < br.x), lt1 = __ballot(x1 < br.x);
-          const unsigned long long in = (__ballot(x0 <= br.y) & ~lt0) | (__ballot(x1 <= br.y) & ~lt1);
-          amb |= in ? (1u << q) : 0u;
-          set_lane<R32>(M0, (unsigned)lt0);
-          set_lane<R32 + 4>(M0, (unsigned)(lt0 >> 32));
-          set_lane<R32>(M1, (unsigned)lt1);
-          set_lane<R32 + 4>(M1, (unsigned)(lt1 >> 32));
-        });
-        if (SCORES || amb) {                                     // exact comparison for the registers concerned
-          const int64_t col0 = n0 + cl0, col1 = n0 + cl1;
+        const int64_t col0 = n0 + cl0, col1 = n0 + cl1;
+        unsigned* mrow = lds.bm + (wm * 64 + tm * 32) * 4 + wn * 2;
+        if constexpr (SCORES) {                                  // tests: every loss exactly, and stored
           const int32_t c0 = col0 < K ? cand[col0] : -1, c1 = col1 < K ? cand[col1] : -1;
           static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
-            if (SCORES || ((amb >> q) & 1u)) {
-              const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
-              unsigned long long e0, e1;
-              exact_masks<SCORES>(lds, acc[tm][0][q] * sb0, acc[tm][1][q] * sb1, rl, c0, c1, e0, e1, scores_out, m0 + rl, B,
-                                  K, col0, col1);
-              set_lane<R32>(M0, (unsigned)e0);
-              set_lane<R32 + 4>(M0, (unsigned)(e0 >> 32));
-              set_lane<R32>(M1, (unsigned)e1);
-              set_lane<R32 + 4>(M1, (unsigned)(e1 >> 32));
-            }
+            const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
+            unsigned long long e0, e1;
+            exact_masks<true>(lds, acc[tm][0][q] * sb0, acc[tm][1][q] * sb1, rl, c0, c1, e0, e1, scores_out, m0 + rl, B, K,
+                              col0, col1);
+            set_lane<R32>(M0, (unsigned)e0);
+            set_lane<R32 + 4>(M0, (unsigned)(e0 >> 32));
+            set_lane<R32>(M1, (unsigned)e1);
+            set_lane<R32 + 4>(M1, (unsigned)(e1 >> 32));
           });
-        }
-        if (lane < 32) {
-          unsigned* m = lds.bm + (wm * 64 + tm * 32 + lane) * 4 + wn * 2;
-          m[0] = (unsigned)M0;
-          m[1] = (unsigned)M1;
+          if (lane < 32) { mrow[lane * 4] = (unsigned)M0; mrow[lane * 4 + 1] = (unsigned)M1; }
+        } else {
+          // Per score: a multiply, "x < lo" (the bit, as a wave mask -> two v_writelane) and "x <= hi".  Both
+          // outcomes are also shifted into per-lane bitmaps (one v_addc each); they differ exactly where a score
+          // sits inside a bracket.  No scalar-unit work: SALU chains on compare results stall the wave.
+          unsigned L = 0, H = 0;
+          static_for<0, 16>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
+            const float2 br = lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh];
+            const float x0 = acc[tm][0][q] * sb0, x1 = acc[tm][1][q] * sb1;
+            const unsigned long long lt0 = __ballot(x0 < br.x), lt1 = __ballot(x1 < br.x);
+            shift_in(L, lt0);
+            shift_in(L, lt1);
+            shift_in(H, __ballot(x0 <= br.y));
+            shift_in(H, __ballot(x1 <= br.y));
+            set_lane<R32>(M0, (unsigned)lt0);
+            set_lane<R32 + 4>(M0, (unsigned)(lt0 >> 32));
+            set_lane<R32>(M1, (unsigned)lt1);
+            set_lane<R32 + 4>(M1, (unsigned)(lt1 >> 32));
+          });
+          if (lane < 32) { mrow[lane * 4] = (unsigned)M0; mrow[lane * 4 + 1] = (unsigned)M1; }
+          const unsigned inb = H ^ L;                            // score (q, tn) of this lane: bit 31 - (2q + tn)
+          if (inb) {                                             // lanes owning a score inside a bracket: the exact
+            const int32_t c0 = col0 < K ? cand[col0] : -1, c1 = col1 < K ? cand[col1] : -1;   // comparison, bit set in LDS
+            static_for<0, 32>([&](auto kc) {
+              constexpr int kk = decltype(kc)::value, q = kk >> 1, tn = kk & 1, R32 = (q & 3) + 8 * (q >> 2);
+              if (inb & (0x80000000u >> kk)) {
+                const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
+                const float e = rank_sigmoid(acc[tm][tn][q] * (tn ? sb1 : sb0) * lds.sA[rl]), et = lds.eT[rl];
+                if (e < et || (e == et && (tn ? c1 : c0) < lds.tI[rl])) atomicOr(mrow + (R32 + 4 * lh) * 4 + tn, 1u << li);
+              }
+            });
+          }
         }
       }
       __syncthreads();
@@ -388,9 +428,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         raw_reg += __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
       }
       if (known_off) {
-        const int64_t tile = (int64_t)rb * n_ct + ct;
-        const int32_t e0 = known_off[tile], e1 = known_off[tile + 1];
-        for (int32_t e = e0 + t; e < e1; e += kBlock) {
+        for (int32_t e = kn0 + t; e < kn1; e += kBlock) {
           const unsigned rc = known_rc[e];
           const int rl = rc >> 7, cl = rc & 127;
           if ((lds.bm[rl * 4 + (cl >> 5)] >> (cl & 31)) & 1u) atomicAdd(&lds.skip[rl], 1);

@@ -41,13 +41,28 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, int ite
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+      if (MODE == 7) { __builtin_amdgcn_sched_barrier(0); v0 = __builtin_fmaf(v0, 1.0001f, 0.5f); v1 = __builtin_fmaf(v1, 0.9999f, 0.25f); __builtin_amdgcn_sched_barrier(0); }
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+      if (MODE == 7) { __builtin_amdgcn_sched_barrier(0); v2 = __builtin_fmaf(v2, 1.0002f, 0.125f); v3 = __builtin_fmaf(v3, 0.9998f, 0.0625f); __builtin_amdgcn_sched_barrier(0); }
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+      if (MODE == 7) { __builtin_amdgcn_sched_barrier(0); v0 = __builtin_fmaf(v0, 1.0001f, 0.5f); v1 = __builtin_fmaf(v1, 0.9999f, 0.25f); __builtin_amdgcn_sched_barrier(0); }
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+      if (MODE == 7) { __builtin_amdgcn_sched_barrier(0); v2 = __builtin_fmaf(v2, 1.0002f, 0.125f); v3 = __builtin_fmaf(v3, 0.9998f, 0.0625f); __builtin_amdgcn_sched_barrier(0); }
       if (MODE == 4 || MODE == 6) {      // 4 independent VALU ops per MFMA group of 4 -> x NV
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < (MODE == 4 ? 2 : 6); ++r) {
+          v0 = __builtin_fmaf(v0, 1.0001f, 0.5f); v1 = __builtin_fmaf(v1, 0.9999f, 0.25f);
+          v2 = __builtin_fmaf(v2, 1.0002f, 0.125f); v3 = __builtin_fmaf(v3, 0.9998f, 0.0625f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (MODE == 7) {                   // the same 128 FMAs as mode 4, one per MFMA ... (placed after each MFMA below)
+      }
+      if (MODE == 8 && s == 0) {         // ... or all in one burst per chunk
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
           v0 = __builtin_fmaf(v0, 1.0001f, 0.5f); v1 = __builtin_fmaf(v1, 0.9999f, 0.25f);
           v2 = __builtin_fmaf(v2, 1.0002f, 0.125f); v3 = __builtin_fmaf(v3, 0.9998f, 0.0625f);
         }
@@ -104,5 +119,7 @@ int main() {
   run<4>("regs + 8 FMAs per 4 MFMAs", out, cyc, iters, src);
   run<6>("regs + 24 FMAs per 4 MFMAs", out, cyc, iters, src);
   run<5>("regs + 4 global dwordx4 per chunk", out, cyc, iters, src);
+  run<7>("regs + 128 FMAs, 2 after every MFMA", out, cyc, iters, src);
+  run<8>("regs + 128 FMAs in one burst", out, cyc, iters, src);
   return 0;
 }
