@@ -27,6 +27,15 @@
 namespace ge {
 namespace {
 
+// compile-time loop: f(integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{})
+template <int I0, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, N>(f);
+  }
+}
+
 template <int CW>
 struct Cfg {
   static constexpr int kGS = 4;                 // k-pairs per operand group (16 MFMAs)
@@ -83,7 +92,7 @@ __device__ __forceinline__ void ops_piece(Ops& o, const float* __restrict__ ap, 
 
 // One 128 x 128 tile: acc = Q . T^T for the candidate rows `cid` (this thread stages row t>>1, half t&1),
 // candidate clip scales to lds.sB.  rA / rB hold chunks 0 and 1 of the row on entry.
-template <int CW>
+template <int CW, int NCH>
 __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64_t N, int d, int lda, int32_t cid,
                                           float max_norm, const PipeLds& lds, float4 (&rA)[Cfg<CW>::kNV],
                                           float4 (&rB)[Cfg<CW>::kNV], f32x16 (&acc)[2][2]) {
@@ -94,7 +103,7 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
   const int li = lane & 31, lh = lane >> 5;
   const bool bad = cid < 0 || cid >= N;
   const float* crow = table + (int64_t)(bad ? 0 : cid) * d + half * (CW / 2);
-  const int n_chunks = d / CW;
+  const int n_chunks = NCH ? NCH : d / CW;                          // NCH: chunks per row known at compile time (0: loop)
   const float* ap0 = lds.A + (wm * 64 + li) * lda + lh;             // this lane's A fragment rows, chunk 0
   const float* bp0 = lds.Bs + (wn * 64 + li) * LDB + lh;            // this lane's B fragment rows, buffer 0
   float* st0 = lds.Bs + srow * LDB + half * (CW / 2);               // this thread's staging slice, buffer 0
@@ -165,16 +174,24 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  int q = 0;
-  for (; q + 2 < n_chunks; q += 2) {                                // register sets swap roles every chunk
-    chunk(B0{}, std::false_type{}, q, rB, rA);
-    chunk(B1{}, std::false_type{}, q + 1, rA, rB);
-  }
-  if (n_chunks - q == 2) {
-    chunk(B0{}, std::false_type{}, q, rB, rA);
-    chunk(B1{}, std::true_type{}, q + 1, rA, rB);
+  if constexpr (NCH > 0) {                                          // straight-line: no accumulator copies at joins
+    static_for<0, NCH>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q & 1) chunk(B1{}, std::bool_constant<q == NCH - 1>{}, q, rA, rB);
+      else chunk(B0{}, std::bool_constant<q == NCH - 1>{}, q, rB, rA);
+    });
   } else {
-    chunk(B0{}, std::true_type{}, q, rB, rA);
+    int q = 0;
+    for (; q + 2 < n_chunks; q += 2) {                              // register sets swap roles every chunk
+      chunk(B0{}, std::false_type{}, q, rB, rA);
+      chunk(B1{}, std::false_type{}, q + 1, rA, rB);
+    }
+    if (n_chunks - q == 2) {
+      chunk(B0{}, std::false_type{}, q, rB, rA);
+      chunk(B1{}, std::true_type{}, q + 1, rA, rB);
+    } else {
+      chunk(B0{}, std::true_type{}, q, rB, rA);
+    }
   }
   float ss = ss2.x + ss2.y;
   ss += __shfl_xor(ss, 1, kWave);
@@ -183,15 +200,6 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
     lds.sB[srow] = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv);
   }
   __syncthreads();
-}
-
-// compile-time loop: f(integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{})
-template <int I0, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I0 < N) {
-    f(std::integral_constant<int, I0>{});
-    static_for<I0 + 1, N>(f);
-  }
 }
 
 // v_writelane_b32 with a constant lane (this clang has no builtin for it): lane `LANE` of m = the wave-uniform v.
@@ -223,7 +231,7 @@ __device__ __forceinline__ void exact_masks(const PipeLds& lds, float x0, float 
   }
 }
 
-template <int CW, bool SCORES>
+template <int CW, int NCH, bool SCORES>
 __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       const int32_t tid = lds.tI[srow];
       pipe_fetch<CW>(table, N, d, tid, 0, rA);
       pipe_fetch<CW>(table, N, d, tid, 1, rB);
-      pipe_tile<CW>(table, N, d, lda, tid, max_norm, lds, rA, rB, acc);
+      pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, lds, rA, rB, acc);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     pipe_fetch<CW>(table, N, d, cid, 1, rB);
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
-      pipe_tile<CW>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);
+      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);
       cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
       pipe_fetch<CW>(table, N, d, cid, 0, rA);                   // land while the epilogue below runs
       pipe_fetch<CW>(table, N, d, cid, 1, rB);
@@ -410,13 +418,22 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
           if (lane < 32) { mrow[lane * 4] = (unsigned)M0; mrow[lane * 4 + 1] = (unsigned)M1; }
           const unsigned inb = H ^ L;                            // score (q, tn) of this lane: bit 31 - (2q + tn)
           if (inb) {                                             // lanes owning a score inside a bracket: the exact
-            const int32_t c0 = col0 < K ? cand[col0] : -1, c1 = col1 < K ? cand[col1] : -1;   // comparison, bit set in LDS
-            static_for<0, 32>([&](auto kc) {
-              constexpr int kk = decltype(kc)::value, q = kk >> 1, tn = kk & 1, R32 = (q & 3) + 8 * (q >> 2);
-              if (inb & (0x80000000u >> kk)) {
-                const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
-                const float e = rank_sigmoid(acc[tm][tn][q] * (tn ? sb1 : sb0) * lds.sA[rl]), et = lds.eT[rl];
-                if (e < et || (e == et && (tn ? c1 : c0) < lds.tI[rl])) atomicOr(mrow + (R32 + 4 * lh) * 4 + tn, 1u << li);
+            static_for<0, 4>([&](auto gc) {                      // comparison, bit set in LDS; 8 scores per outer test
+              constexpr int g8 = decltype(gc)::value;
+              if (inb & (0xff000000u >> (8 * g8))) {
+                static_for<0, 8>([&](auto kc) {
+                  constexpr int kk = 8 * g8 + decltype(kc)::value, q = kk >> 1, tn = kk & 1, R32 = (q & 3) + 8 * (q >> 2);
+                  if (inb & (0x80000000u >> kk)) {
+                    const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
+                    const float e = rank_sigmoid(acc[tm][tn][q] * (tn ? sb1 : sb0) * lds.sA[rl]), et = lds.eT[rl];
+                    bool before = e < et;
+                    if (e == et) {                               // equal losses pop in id order
+                      const int64_t col = tn ? col1 : col0;
+                      before = (col < K ? cand[col] : -1) < lds.tI[rl];
+                    }
+                    if (before) atomicOr(mrow + (R32 + 4 * lh) * 4 + tn, 1u << li);
+                  }
+                });
               }
             });
           }
@@ -470,7 +487,9 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                        cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles);
     return launch_status();
   };
-  return scores_out ? go(rank_pipe_kernel<CW, true>) : go(rank_pipe_kernel<CW, false>);
+  if (scores_out) return go(rank_pipe_kernel<CW, 0, true>);
+  if (CW == 40 && d == 200) return go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), false>);   // the FB15k configuration, unrolled
+  return go(rank_pipe_kernel<CW, 0, false>);
 }
 
 }  // namespace
