@@ -400,30 +400,30 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
           // Per score: a multiply, "x < lo" (the bit, as a wave mask -> two v_writelane) and "x <= hi".  Both
           // outcomes are also shifted into per-lane bitmaps (one v_addc each); they differ exactly where a score
           // sits inside a bracket.  No scalar-unit work: SALU chains on compare results stall the wave.
-          unsigned L = 0, H = 0;
+          unsigned L0 = 0, L1 = 0, H0 = 0, H1 = 0;               // four independent chains
           static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
             const float2 br = lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh];
             const float x0 = acc[tm][0][q] * sb0, x1 = acc[tm][1][q] * sb1;
             const unsigned long long lt0 = __ballot(x0 < br.x), lt1 = __ballot(x1 < br.x);
-            shift_in(L, lt0);
-            shift_in(L, lt1);
-            shift_in(H, __ballot(x0 <= br.y));
-            shift_in(H, __ballot(x1 <= br.y));
+            shift_in(L0, lt0);
+            shift_in(L1, lt1);
+            shift_in(H0, __ballot(x0 <= br.y));
+            shift_in(H1, __ballot(x1 <= br.y));
             set_lane<R32>(M0, (unsigned)lt0);
             set_lane<R32 + 4>(M0, (unsigned)(lt0 >> 32));
             set_lane<R32>(M1, (unsigned)lt1);
             set_lane<R32 + 4>(M1, (unsigned)(lt1 >> 32));
           });
           if (lane < 32) { mrow[lane * 4] = (unsigned)M0; mrow[lane * 4 + 1] = (unsigned)M1; }
-          const unsigned inb = H ^ L;                            // score (q, tn) of this lane: bit 31 - (2q + tn)
-          if (inb) {                                             // lanes owning a score inside a bracket: the exact
+          const unsigned in0 = H0 ^ L0, in1 = H1 ^ L1;           // score (q, tn) of this lane: bit 15 - q of in<tn>
+          if (in0 | in1) {                                       // lanes owning a score inside a bracket: the exact
             static_for<0, 4>([&](auto gc) {                      // comparison, bit set in LDS; 8 scores per outer test
-              constexpr int g8 = decltype(gc)::value;
-              if (inb & (0xff000000u >> (8 * g8))) {
+              constexpr int g4 = decltype(gc)::value;
+              if ((in0 | in1) & (0xf000u >> (4 * g4))) {
                 static_for<0, 8>([&](auto kc) {
-                  constexpr int kk = 8 * g8 + decltype(kc)::value, q = kk >> 1, tn = kk & 1, R32 = (q & 3) + 8 * (q >> 2);
-                  if (inb & (0x80000000u >> kk)) {
+                  constexpr int kk = decltype(kc)::value, q = 4 * g4 + (kk >> 1), tn = kk & 1, R32 = (q & 3) + 8 * (q >> 2);
+                  if ((tn ? in1 : in0) & (0x8000u >> q)) {
                     const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
                     const float e = rank_sigmoid(acc[tm][tn][q] * (tn ? sb1 : sb0) * lds.sA[rl]), et = lds.eT[rl];
                     bool before = e < et;

@@ -20,9 +20,9 @@ rep("  while (idx < idx_end) {\n    const int rb",
 rep("    __syncthreads();\n\n    f32x16 acc[2][2];",
     "    __syncthreads();\n    T_setup += clock64() - T0; T0 = clock64();\n\n    f32x16 acc[2][2];")
 rep("    int raw_reg = 0;\n", "    int raw_reg = 0;\n    T_diag += clock64() - T0;\n")
-rep("      const int64_t n0 = (int64_t)ct * kRB;\n      pipe_tile<CW>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);\n",
+rep("      const int64_t n0 = (int64_t)ct * kRB;\n      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);\n",
     "      const int64_t n0 = (int64_t)ct * kRB;\n      T0 = clock64();\n"
-    "      pipe_tile<CW>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);\n"
+    "      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);\n"
     "      T_tile += clock64() - T0; T0 = clock64(); ++n_t;\n")
 rep("      __syncthreads();\n      if (t < kRB) {\n        const unsigned* m = lds.bm + t * 4;",
     "      T_epi += clock64() - T0; T0 = clock64();\n      __syncthreads();\n      if (t < kRB) {\n"
