@@ -24,6 +24,10 @@
 
 #include "ge_rank_dev.h"
 
+#ifndef GE_PIPE_GRID_M
+#define GE_PIPE_GRID_M 2   // workgroups per CU (each CU holds one at a time): equal shares, two rounds
+#endif
+
 namespace ge {
 namespace {
 
@@ -478,7 +482,7 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
   if (n_ct > INT32_MAX / 2 || n_rb > INT32_MAX / 2) return GE_ENOTSUP;
   const int64_t n_tiles = n_rb * n_ct;
-  const int64_t grid = std::min<int64_t>(n_tiles, 2 * (int64_t)pipe_cu_count());
+  const int64_t grid = std::min<int64_t>(n_tiles, GE_PIPE_GRID_M * (int64_t)pipe_cu_count());
   auto go = [&](auto kern) -> int {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);

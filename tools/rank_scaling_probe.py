@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from graphembeddings_amd import _lib
+if os.environ.get("GE_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["GE_LIB"])
 from graphembeddings_amd import hole as H
 N, R, B = 16296, 1345, 59071
 g = torch.Generator(device="cuda").manual_seed(0)
