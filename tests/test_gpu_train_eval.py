@@ -52,21 +52,25 @@ def _all_scores(emb, test, cand, side, fused):
     return H.score_candidates(emb, hr, c, cand_is_head=(side == "head")).cpu().numpy()
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_gpu_ranks_equal_reference_heap_semantics(fused):
+@pytest.mark.parametrize("fused,d", [(True, 64), (False, 64), (True, 56), (True, 120), (True, 48), (True, 40)])
+def test_gpu_ranks_equal_reference_heap_semantics(fused, d):
     """Raw and filtered ranks (counted in the GEMM epilogue when fused, with tensor ops on the stored scores
     otherwise) equal the reference's heap (holE.py:427-472, oracle restatement) fed with the same losses,
-    exact ties included; the losses themselves are within 1e-5 of the fp64 oracle."""
+    exact ties included; the losses themselves are within 1e-5 of the fp64 oracle.  embedding_dim 64 / 120 / 48 /
+    40 run the pipelined kernel with chunk widths 32 / 40 / 24 / 40 (two, three, two, one chunk), 56 the generic one."""
     from graphembeddings_amd import evaluate as E
     rng = np.random.default_rng(1)
-    R, N, d = 5, 405, 64
+    R, N = 5, 405
     table = (rng.standard_normal((N, d)) * 0.2).astype(np.float32)
     table[50] = table[51]                                   # exact score ties between candidates
     table[60] = table[61]
+    for j in range(70, 90):                                 # near-duplicates of row 52: scores a few ulps apart, inside the
+        table[j] = table[52] * np.float32(1.0 + 2e-7 * (j - 79.5))   # raw-score bracket of the pipelined kernel's epilogue
     emb = torch.as_tensor(table).cuda()
     B = 150                                                 # two row blocks of the fused kernel
     test = np.stack([rng.integers(R, N, B), rng.integers(R, N, B), rng.integers(0, R, B)], 1)
     test[:4, 1] = [50, 51, 60, 61]                          # targets that tie with another candidate
+    test[4:12, 1] = [52, 70, 75, 79, 80, 84, 89, 52]        # targets among the near-duplicates
     known = np.stack([np.repeat(test[:, 0], 6), rng.integers(R, N, 6 * B), np.repeat(test[:, 2], 6)], 1)
     known = known[~(known[:, None, :] == test[None, :, :]).all(-1).any(1)]      # test tails are not "known"
     cand = np.arange(R, N)
