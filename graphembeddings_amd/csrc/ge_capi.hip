@@ -9,7 +9,7 @@ int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, co
 int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
 int complex_max_dim();
 int rank_max_dim();
-int complex_rank_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float, int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, hipStream_t);
+int complex_rank_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float, int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, hipStream_t);
 int hole_spectral_launch(float*, int64_t, int32_t, int, hipStream_t);
 int hole_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
 int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t);
@@ -205,11 +205,12 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
 
 int ge_rank_max_dim(void) { return rank_max_dim(); }
 
-int ge_complex_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
-                        const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
-                        const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
-                        float* scores_out, void* stream) {
+int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head, const int32_t* known_off,
+                const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
+                float* scores_out, void* stream) {
   if (B < 0 || K < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (model != GE_MODEL_COMPLEX && model != GE_MODEL_HOLE_SPECTRAL) return model == GE_MODEL_HOLE || model == GE_MODEL_HOLE_DIRECT ? GE_ENOTSUP : GE_EINVAL;
   if (B > 0 && (!hr || !true_id || !n_before || !n_known_before)) return GE_EINVAL;
   if (B > 0 && K > 0 && !cand) return GE_EINVAL;
   if ((known_off == nullptr) != (known_rc == nullptr)) return GE_EINVAL;
@@ -219,7 +220,15 @@ int ge_complex_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t*
   if (e == hipSuccess) e = hipMemsetAsync(n_known_before, 0, sizeof(int32_t) * (size_t)B, st);
   if (e != hipSuccess) return (int)e;
   return complex_rank_1vK_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,
-                                 n_before, n_known_before, true_loss, scores_out, st);
+                                 n_before, n_known_before, true_loss, scores_out, model == GE_MODEL_HOLE_SPECTRAL, st);
+}
+
+int ge_complex_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                        const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
+                        const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
+                        float* scores_out, void* stream) {
+  return ge_rank_1vK(table, N, d, hr, B, true_id, cand, K, max_norm, GE_MODEL_COMPLEX, cand_is_head, known_off, known_rc,
+                     n_before, n_known_before, true_loss, scores_out, stream);
 }
 
 int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, int64_t T, int64_t first_row,

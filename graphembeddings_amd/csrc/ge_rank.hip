@@ -83,13 +83,14 @@ __device__ __forceinline__ void rank_fetch(const float* __restrict__ table, int6
 // 64-cycle matrix instruction before it: iteration ch stores chunk ch+1 (registers, requested an iteration
 // ago) to the free LDS buffer in 8 slices, then requests chunk ch+2 in 4 slices.  sched_barriers pin the order.
 __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64_t N, int d, int lda,
-                                          int32_t cid, float max_norm, const RankLds& lds, float4 (&rA)[4],
+                                          int32_t cid, float max_norm, int spec, const RankLds& lds, float4 (&rA)[4],
                                           float4 (&rB)[4], f32x16 (&acc)[2][2]) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int srow = t >> 1, half = t & 1;
   const int li = lane & 31, lh = lane >> 5;
   const bool bad = cid < 0 || cid >= N;
   const float* crow = table + (int64_t)(bad ? 0 : cid) * d;
+  const float x_dc = crow[0], x_ny = crow[d >> 1];   // spectral HolE rows: |x|^2 = (2 sum - X_0^2 - X_k^2) / d
   const int n_chunks = (d + kChunk - 1) / kChunk;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -172,6 +173,7 @@ __device__ __forceinline__ void rank_tile(const float* __restrict__ table, int64
     __syncthreads();
   }
   ss += __shfl_xor(ss, 1, kWave);
+  if (spec) ss = (2.f * ss - x_dc * x_dc - x_ny * x_ny) / (float)d;
   if (half == 0) {
     float inv;
     lds.sB[srow] = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
     int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
-    float* __restrict__ scores_out, int lda) {
+    float* __restrict__ scores_out, int lda, int spec) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RankLds lds;
   lds.A = smem;
@@ -216,31 +218,40 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     float* arow = lds.A + srow * lda;
     const int kh = (k + 1) / 2;                                  // complex dims per staging thread
     const int c_lo = half * kh, c_hi = min(k, (half + 1) * kh);
+    // spectral HolE (ge_complex_dev.h): Hermitian weight 2 on every bin but element 0, which packs the two REAL
+    // bins X_0 | X_k; norms and score carry the Parseval factor 1/d
     for (int c = c_lo; c < c_hi; ++c) {                          // pass 1: the two clip norms
       const float fre = bad ? 0.f : frow[c], fim = bad ? 0.f : frow[k + c];
       const float rre = bad ? 0.f : rrow[c], rim = bad ? 0.f : rrow[k + c];
-      ssf += fre * fre + fim * fim;
-      ssr += rre * rre + rim * rim;
+      const float wgt = (spec && c != 0) ? 2.f : 1.f;
+      ssf += wgt * (fre * fre + fim * fim);
+      ssr += wgt * (rre * rre + rim * rim);
     }
     ssf += __shfl_xor(ssf, 1, kWave);
     ssr += __shfl_xor(ssr, 1, kWave);
+    const float inv_d = spec ? 1.0f / (float)d : 1.0f;
     float i0, i1;
     // the product of the fixed row's and the relation row's clip scales is folded into Q (NaN: bad ids / beyond B,
     // which makes every loss of the row NaN and every comparison false)
-    const float sa = (bad || r >= B) ? __builtin_nanf("") : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+    const float sa = (bad || r >= B) ? __builtin_nanf("")
+                                     : clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d;
     for (int c = c_lo; c < c_hi; ++c) {                          // pass 2: q = fixed o relation, scaled
       const float fre = bad ? 0.f : frow[c], fim = bad ? 0.f : frow[k + c];
       const float rre = bad ? 0.f : rrow[c], rim = bad ? 0.f : rrow[k + c];
       float qre, qim;
-      if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
+      if (spec && c == 0) {  // two independent real dimensions
+        qre = fre * rre;
+        qim = fim * rim;
+      } else if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
         qre = fre * rre - fim * rim;
         qim = fre * rim + fim * rre;
       } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
         qre = rre * fre + rim * fim;
         qim = -(rim * fre - rre * fim);
       }
-      arow[c] = qre * sa;
-      arow[k + c] = qim * sa;
+      const float wgt = (spec && c != 0) ? 2.f : 1.f;
+      arow[c] = qre * sa * wgt;
+      arow[k + c] = qim * sa * wgt;
     }
     if (half == 0) {
       lds.skip[srow] = 0;
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
   {
     rank_fetch(table, N, d, lds.tI[srow], 0, rA);
     rank_fetch(table, N, d, lds.tI[srow], 1, rB);
-    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, lds, rA, rB, acc);
+    rank_tile(table, N, d, lda, lds.tI[srow], max_norm, spec, lds, rA, rB, acc);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
   rank_fetch(table, N, d, cid, 1, rB);
   for (int ct = blockIdx.x; ct < n_ct; ct += gridDim.x) {
     const int64_t n0 = (int64_t)ct * kRB;
-    rank_tile(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);
+    rank_tile(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
     cid = cand_of(ct + gridDim.x);
     rank_fetch(table, N, d, cid, 0, rA);                         // land while the epilogue below runs
     rank_fetch(table, N, d, cid, 1, rB);
@@ -344,14 +355,14 @@ int rank_max_dim() { return 232; }   // Q (128 x (d+1) floats) + two candidate c
 int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                             const int32_t* true_id, const int32_t* cand, int64_t K, float max_norm, int cand_is_head,
                             const int32_t* known_off, const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt,
-                            float* true_loss, float* scores_out, hipStream_t st) {
+                            float* true_loss, float* scores_out, int spec, hipStream_t st) {
   if (d <= 0 || (d & 7)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;   // 16-byte candidate loads, 8-float tail
   if (d > rank_max_dim()) return GE_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
   if (B == 0 || K == 0) return 0;
   {  // embedding_dim a multiple of 40, 32 or 24: the software-pipelined kernel (ge_rank_pipe.hip)
     const int rc = rank_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,
-                                    raw_cnt, skip_cnt, true_loss, scores_out, st);
+                                    raw_cnt, skip_cnt, true_loss, scores_out, spec, st);
     if (rc != GE_ENOTSUP) return rc;
   }
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
@@ -366,7 +377,7 @@ int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int3
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(rank_1vK_kernel, dim3((unsigned)splits, (unsigned)n_rb), dim3(kBlock), lds, st, table, N, d, hr, B,
                      true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss,
-                     scores_out, d + 1);
+                     scores_out, d + 1, spec);
   return launch_status();
 }
 

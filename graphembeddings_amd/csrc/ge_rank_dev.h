@@ -16,11 +16,11 @@ __device__ __forceinline__ float rank_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
 
-// ge_rank_pipe.hip.  Returns GE_ENOTSUP when embedding_dim has no pipelined instantiation (the caller then uses
+// ge_rank_pipe.hip.  spec: the table is a spectral HolE table (ge_hole_to_spectral).  Returns GE_ENOTSUP when embedding_dim has no pipelined instantiation (the caller then uses
 // the generic kernel), 0 / an error otherwise.
 int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                     float* scores_out, hipStream_t st);
+                     float* scores_out, int spec, hipStream_t st);
 
 }  // namespace ge

@@ -98,8 +98,9 @@ __device__ __forceinline__ void ops_piece(Ops& o, const float* __restrict__ ap, 
 // candidate clip scales to lds.sB.  rA / rB hold chunks 0 and 1 of the row on entry.
 template <int CW, int NCH>
 __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64_t N, int d, int lda, int32_t cid,
-                                          float max_norm, const PipeLds& lds, float4 (&rA)[Cfg<CW>::kNV],
-                                          float4 (&rB)[Cfg<CW>::kNV], f32x16 (&acc)[2][2]) {
+                                          float max_norm, int spec, const PipeLds& lds,
+                                          float4 (&rA)[Cfg<CW>::kNV], float4 (&rB)[Cfg<CW>::kNV],
+                                          f32x16 (&acc)[2][2]) {
   using C = Cfg<CW>;
   constexpr int NG = C::kNG, NV = C::kNV, LDB = C::kLdb;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
@@ -107,6 +108,9 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
   const int li = lane & 31, lh = lane >> 5;
   const bool bad = cid < 0 || cid >= N;
   const float* crow = table + (int64_t)(bad ? 0 : cid) * d + half * (CW / 2);
+  // spectral HolE rows (ge_complex_dev.h): |x|^2 = (2 sum - X_0^2 - X_k^2) / d.  Both reals are requested here,
+  // unconditionally, and used at the end of the tile.
+  const float x_dc = crow[-half * (CW / 2)], x_ny = crow[-half * (CW / 2) + (d >> 1)];
   const int n_chunks = NCH ? NCH : d / CW;                          // NCH: chunks per row known at compile time (0: loop)
   const float* ap0 = lds.A + (wm * 64 + li) * lda + lh;             // this lane's A fragment rows, chunk 0
   const float* bp0 = lds.Bs + (wn * 64 + li) * LDB + lh;            // this lane's B fragment rows, buffer 0
@@ -199,6 +203,7 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
   }
   float ss = ss2.x + ss2.y;
   ss += __shfl_xor(ss, 1, kWave);
+  if (spec) ss = (2.f * ss - x_dc * x_dc - x_ny * x_ny) / (float)d;
   if (half == 0) {
     float inv;
     lds.sB[srow] = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv);
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
     int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
-    float* __restrict__ scores_out, int n_ct, int64_t n_tiles) {
+    float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec) {
   using C = Cfg<CW>;
   constexpr int NV = C::kNV;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -290,25 +295,33 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         const float rr[4] = {rre.x, rre.y, rre.z, rre.w}, ri[4] = {rim.x, rim.y, rim.z, rim.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          ssf += fr[i] * fr[i] + fi[i] * fi[i];
-          ssr += rr[i] * rr[i] + ri[i] * ri[i];
+          // spectral HolE: Hermitian weight 2 on every bin but element 0, which packs the two REAL bins X_0 | X_k
+          const bool packed = spec && j == 0 && i == 0;
+          const float wgt = (spec && !packed) ? 2.f : 1.f;
+          ssf += wgt * (fr[i] * fr[i] + fi[i] * fi[i]);
+          ssr += wgt * (rr[i] * rr[i] + ri[i] * ri[i]);
           float qre, qim;
-          if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
+          if (packed) {          // two independent real dimensions: products of the re slots and of the im slots
+            qre = fr[i] * rr[i];
+            qim = fi[i] * ri[i];
+          } else if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
             qre = fr[i] * rr[i] - fi[i] * ri[i];
             qim = fr[i] * ri[i] + fi[i] * rr[i];
           } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
             qre = rr[i] * fr[i] + ri[i] * fi[i];
             qim = -(ri[i] * fr[i] - rr[i] * fi[i]);
           }
-          arow[4 * j + i] = qre;
-          arow[k + 4 * j + i] = qim;
+          arow[4 * j + i] = qre * wgt;
+          arow[k + 4 * j + i] = qim * wgt;
         }
       }
       ssf += __shfl_xor(ssf, 1, kWave);
       ssr += __shfl_xor(ssr, 1, kWave);
       if (half == 0) {
         float i0, i1;
-        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+        const float inv_d = spec ? 1.0f / (float)d : 1.0f;   // Parseval / correlation-theorem factor of the spectral form
+        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("")
+                                       : clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d;
         lds.skip[srow] = 0;
         lds.tI[srow] = r < B ? true_id[r] : -1;
       }
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       const int32_t tid = lds.tI[srow];
       pipe_fetch<CW>(table, N, d, tid, 0, rA);
       pipe_fetch<CW>(table, N, d, tid, 1, rB);
-      pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, lds, rA, rB, acc);
+      pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, spec, lds, rA, rB, acc);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     pipe_fetch<CW>(table, N, d, cid, 1, rB);
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
-      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);
+      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
       cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
       pipe_fetch<CW>(table, N, d, cid, 0, rA);                   // land while the epilogue below runs
       pipe_fetch<CW>(table, N, d, cid, 1, rB);
@@ -476,7 +489,7 @@ template <int CW>
 int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                    const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                    const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss, float* scores_out,
-                   hipStream_t st) {
+                   int spec, hipStream_t st) {
   const size_t lds = pipe_lds_bytes<CW>(d);
   if (lds > 160 * 1024) return GE_ENOTSUP;
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
@@ -488,7 +501,7 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, table, N, d, hr, B, true_id, cand, K, max_norm,
-                       cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles);
+                       cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec);
     return launch_status();
   };
   if (scores_out) return go(rank_pipe_kernel<CW, 0, true>);
@@ -501,10 +514,10 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
 int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                     float* scores_out, hipStream_t st) {
+                     float* scores_out, int spec, hipStream_t st) {
 #define GE_PIPE(CW)                                                                                                  \
   return pipe_launch_cw<CW>(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt, \
-                            skip_cnt, true_loss, scores_out, st)
+                            skip_cnt, true_loss, scores_out, spec, st)
   if (d % 40 == 0) GE_PIPE(40);
   if (d % 32 == 0) GE_PIPE(32);
   if (d % 24 == 0) GE_PIPE(24);

@@ -75,18 +75,30 @@ class KnownIndex:
 @torch.no_grad()
 def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, candidates: np.ndarray,
                           known_triples: np.ndarray = None, side: str = "tail", batch: int = 16384,
-                          max_norm: float = 1.0, fused: bool = None):
+                          max_norm: float = 1.0, fused: bool = None, model: str = "complex"):
     """Raw and filtered rank of every test triple's true entity among `candidates`, with the
     semantics of holE.py:446-469.  side="tail": candidates replace the tail; "head": the head.
     Returns (raw_ranks, filtered_ranks) int64 arrays.  The true entity must be a candidate.
     fused (default: whenever the kernel supports embedding_dim): the ranks are counted in the candidate
     GEMM's epilogue (ge_complex_rank_1vK) and no [B,K] score matrix is materialised; otherwise the scores
-    of ge_complex_score_1vK are ranked with tensor ops."""
+    of ge_complex_score_1vK are ranked with tensor ops.
+    model: "complex"; "hole" (README.md:42 on a real-valued table: a copy is taken to the frequency domain once,
+    where HolE is the ComplEx-shaped form the sweep computes) or "hole_spectral" (table already there).  HolE
+    needs the fused sweep."""
     assert side in ("tail", "head")
+    if model not in ("complex", "hole", "hole_spectral"):
+        raise ValueError(f"unknown model {model!r}")
     dev = embeddings.device
     d = embeddings.shape[1]
+    can_fuse = d % 8 == 0 and d <= H.rank_max_dim()
     if fused is None:
-        fused = d % 8 == 0 and d <= H.rank_max_dim()
+        fused = can_fuse
+    if model != "complex":
+        if not (fused and can_fuse):
+            raise ValueError("HolE link prediction needs the fused sweep: embedding_dim a multiple of 8, <= %d" % H.rank_max_dim())
+        if model == "hole":
+            embeddings = H.hole_to_spectral(embeddings.detach().clone())
+        model = "hole_spectral"
     test = np.asarray(test_triples, dtype=np.int64)
     cand = torch.as_tensor(np.asarray(candidates, dtype=np.int32)).to(dev)
     cand64 = cand.to(torch.int64)
@@ -106,7 +118,7 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
         off, rc = index.cells(fixed, rel, pos_of, cand.numel())
         if fused:
             n_before, n_known = H.rank_candidates(embeddings, hr, true_id, cand, known_off=off, known_rc=rc,
-                                                  cand_is_head=(side == "head"), max_norm=max_norm)
+                                                  cand_is_head=(side == "head"), max_norm=max_norm, model=model)
             raw = n_before.to(torch.int64) + 1
             fil = raw - n_known.to(torch.int64)
         else:
@@ -131,17 +143,19 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
 
 
 def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True, batch: int = 16384,
-                         verbose: bool = True) -> dict:
+                         verbose: bool = True, model: str = "complex") -> dict:
     """Filtered link prediction over all entities (rows >= relation_count) for
     data.test_array, filtering train+valid triples as the reference does (holE.py:413-422)."""
     R, N = data.relation_count, data.entity_count
     cand = np.arange(R, N, dtype=np.int32)
     parts = [a for a in (data.triples, data.validation_triples) if a is not None]
     known = np.concatenate(parts, 0) if parts else None
-    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known, "tail", batch)
+    if model == "hole":                      # one transform for both sides
+        embeddings, model = H.hole_to_spectral(embeddings.detach().clone()), "hole_spectral"
+    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known, "tail", batch, model=model)
     raw, fil = [raw_t], [fil_t]
     if both_sides:
-        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known, "head", batch)
+        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known, "head", batch, model=model)
         raw.append(raw_h); fil.append(fil_h)
     out = mrr_and_hits(np.concatenate(raw), np.concatenate(fil))
     if verbose:

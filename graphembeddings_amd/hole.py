@@ -352,12 +352,15 @@ def rank_max_dim() -> int:
 def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, true_ids: torch.Tensor,
                     candidates: torch.Tensor, *, known_off: Optional[torch.Tensor] = None,
                     known_rc: Optional[torch.Tensor] = None, cand_is_head: bool = False, max_norm: float = 1.0,
-                    return_true_loss: bool = False, return_scores: bool = False):
+                    return_true_loss: bool = False, return_scores: bool = False, model: str = "complex"):
     """The candidate sweep of holE.py:564-569 with the ranking of holE.py:427-472 as its epilogue
     (ge_complex_rank_1vK): per test row the number of candidates that pop from the reference's heap before the
     true one (n_before; raw rank = 1 + n_before) and how many of those are known-true (n_known_before; filtered
     rank = raw - n_known_before).  No [B,K] score matrix exists unless return_scores asks for it (tests).
-    known_off / known_rc: the per-(128 rows x 128 candidates)-tile lists of known-true cells (evaluate.py)."""
+    known_off / known_rc: the per-(128 rows x 128 candidates)-tile lists of known-true cells (evaluate.py).
+    model: "complex", or "hole_spectral" for a table held in the frequency domain (hole_to_spectral)."""
+    if model not in ("complex", "hole_spectral"):
+        raise ValueError("rank_candidates: model must be 'complex' or 'hole_spectral' (transform a real HolE table first)")
     emb = _table(embeddings)
     for name, t in (("fixed_and_relation", fixed_and_relation), ("true_ids", true_ids), ("candidates", candidates)):
         _need_cuda(t, name)
@@ -377,8 +380,8 @@ def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, 
         n_tiles = ((B + 127) // 128) * ((K + 127) // 128)
         if known_off.dtype != torch.int32 or known_off.numel() != n_tiles + 1 or known_rc.dtype != torch.int16:
             raise ValueError("known_off must be int32 [tiles+1], known_rc int16 (row%128 << 7 | col%128)")
-    _lib.call("ge_complex_rank_1vK", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), B, tid.data_ptr(),
-              cand.data_ptr(), K, max_norm, int(cand_is_head),
+    _lib.call("ge_rank_1vK", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), B, tid.data_ptr(),
+              cand.data_ptr(), K, max_norm, _MODELS[model], int(cand_is_head),
               known_off.data_ptr() if known_off is not None else None,
               known_rc.data_ptr() if known_rc is not None else None, n_before.data_ptr(), n_known.data_ptr(),
               tl.data_ptr() if tl is not None else None, sc.data_ptr() if sc is not None else None, _stream())

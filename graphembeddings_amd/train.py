@@ -191,7 +191,8 @@ def infer_triples(FLAGS, log=print) -> dict:
     holE.py:534-541)."""
     data = D.init_inference_data(FLAGS.data_dir, min_mentions=None)
     emb, _ = load_checkpoint(FLAGS.output_dir)
-    return E.evaluate_fb15k_style(emb, data, both_sides=True)
+    # --model hole: the checkpoint holds the real-valued table; ranks use the HolE score (README.md:42), not ComplEx
+    return E.evaluate_fb15k_style(emb, data, both_sides=True, model=FLAGS.model)
 
 
 def main(argv=None):

@@ -199,6 +199,14 @@ int ge_complex_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t*
                         const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                         const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                         float* scores_out, void* stream);
+/* The same sweep for `model` GE_MODEL_COMPLEX or GE_MODEL_HOLE_SPECTRAL (the README.md:42 HolE score on a table
+ * held in the frequency domain, ge_hole_to_spectral: the ComplEx-shaped trilinear form with Hermitian weights, so
+ * the candidate operand is still the row exactly as stored).  A real-valued HolE table (GE_MODEL_HOLE /
+ * GE_MODEL_HOLE_DIRECT) is GE_ENOTSUP: transform a copy first. */
+int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head, const int32_t* known_off,
+                const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
+                float* scores_out, void* stream);
 
 /* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
  * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already

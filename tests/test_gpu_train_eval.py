@@ -103,6 +103,54 @@ def test_gpu_ranks_equal_reference_heap_semantics(fused, d):
             assert [raw[i]] == rp and [fil[i]] == fp, (side, i, raw[i], rp, fil[i], fp)
 
 
+@pytest.mark.parametrize("d", [64, 40, 56])
+def test_hole_ranks_from_the_spectral_sweep(d):
+    """HolE link prediction (README.md:42 score): the sweep on the table held in the frequency domain gives losses
+    within 1e-5 of the oracle's FFT-based HolE score on the REAL table, and ranks equal to the reference heap fed with
+    the kernel's own losses -- tails and heads, pipelined kernel (d = 64, 40) and generic kernel (d = 56)."""
+    from graphembeddings_amd import evaluate as E
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(5)
+    R, N = 4, 300
+    table = (rng.standard_normal((N, d)) * 0.25).astype(np.float32)     # some rows above the clip norm, some below
+    table[::7] *= 0.2
+    emb = torch.as_tensor(table).cuda()
+    spec = H.hole_to_spectral(emb.clone())
+    B = 140
+    test = np.stack([rng.integers(R, N, B), rng.integers(R, N, B), rng.integers(0, R, B)], 1)
+    known = np.stack([np.repeat(test[:, 0], 3), rng.integers(R, N, 3 * B), np.repeat(test[:, 2], 3)], 1)
+    known = known[~(known[:, None, :] == test[None, :, :]).all(-1).any(1)]
+    cand = np.arange(R, N)
+    c = torch.as_tensor(cand.astype(np.int32)).cuda()
+    t64 = table.astype(np.float64)
+    for side in ("tail", "head"):
+        kn = known if side == "tail" else known[:, [1, 0, 2]]
+        raw, fil = E.link_prediction_ranks(emb, test, cand, kn, side=side, model="hole")
+        fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
+        hr = torch.as_tensor(np.stack([test[:, fixed_col], test[:, 2]], 1).astype(np.int32)).cuda()
+        tid = torch.as_tensor(test[:, true_col].astype(np.int32)).cuda()
+        scores = H.rank_candidates(spec, hr, tid, c, cand_is_head=(side == "head"), return_scores=True,
+                                   model="hole_spectral")[2].cpu().numpy()
+        for i, (h, t, r) in enumerate(test):
+            if side == "tail":
+                triples = np.stack([np.full(len(cand), h), cand, np.full(len(cand), r)], 1)
+                heap_triples = triples
+                true = O.triple_dict(kn[(kn[:, 0] == h) & (kn[:, 2] == r)])
+                tst = O.triple_dict([[h, t, r]])
+            else:
+                triples = np.stack([cand, np.full(len(cand), t), np.full(len(cand), r)], 1)
+                heap_triples = np.stack([np.full(len(cand), t), cand, np.full(len(cand), r)], 1)
+                true = O.triple_dict(kn[(kn[:, 1] == t) & (kn[:, 2] == r)][:, [1, 0, 2]])
+                tst = O.triple_dict([[t, h, r]])
+            if i < 25:
+                assert np.abs(scores[i] - O.hole_evaluate_triples(triples, t64)[:, 0]).max() < 1e-5
+            rp, fp = [], []
+            O.eval_link_prediction(scores[i], heap_triples, true, tst, rp, fp)
+            assert [raw[i]] == rp and [fil[i]] == fp, (side, i, raw[i], rp, fil[i], fp)
+    with pytest.raises(ValueError):
+        E.link_prediction_ranks(emb, test, cand, known, model="hole", fused=False)
+
+
 def test_fused_and_unfused_rankers_agree_at_fb15k_scale():
     """Full-width sweep (14,951 candidates, 117 column tiles, d = 200): the epilogue-counted ranks and the
     ranks from stored scores differ only where two candidates' losses are within a few ulps of each other in one
