@@ -39,6 +39,12 @@ SYMBOLS = {
     "ge_corrupt_batch": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _u64, _u64, _i32, _i32, _p, _p]),
     "ge_bernoulli_corrupt_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _u64, _u64, _p, _p]),
     "ge_complex_score_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _f, C.c_int, C.c_int, _p, _p]),
+    "ge_plan_keys": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p, C.c_int, _p]),
+    "ge_plan_flags": (C.c_int, [_p, _i64, C.c_int, _p, _p]),
+    "ge_plan_heads": (C.c_int, [_p, _p, _i64, C.c_int, _i64, _p, _p, _p, _p]),
+    "ge_plan_scatter": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "ge_plan_item_counts": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "ge_plan_items": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "ge_rank_max_dim": (C.c_int, []),
     "ge_complex_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "ge_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p]),

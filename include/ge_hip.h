@@ -208,6 +208,38 @@ int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int
                 const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                 float* scores_out, void* stream);
 
+/* --- the exchange planner of the row-sharded step (graphembeddings_amd/sharded.py).  For a chunk of S
+ * steps of B positives and B negatives per rank (pos, neg [S,B,3] int32; negatives never depend on the table, so this
+ * runs ahead of training): a sort of step-tagged row keys -- done by the host with its device sort -- yields per
+ * step the distinct rows to fetch grouped by owner, the position of each of the 6B gradient slots' rows in the
+ * staging buffer, and the work items of ge_segment_sum_rows.  These are the single-pass kernels around that sort:
+ *   ge_plan_keys         key[s*6B + j] = ((s*G + id % G) * N + id) for the j-th id of step s (pos[s] flattened, then
+ *                        neg[s]; ids outside [0,N) alias row 0), int64 or int32 (key64 = 0 needs S*G*N < 2^31)
+ *   ge_plan_flags        flag[i] = 1 where a run of equal sorted keys starts
+ *   ge_plan_heads        with incl = inclusive scan of flag: per run u its first sorted position first_pos[u]
+ *                        (first_pos[U] = n), quot[u] = key / div, rem[u] = key % div
+ *   ge_plan_scatter      remap[perm[i]] = run index of sorted position i minus its step's first run (-1 for an invalid
+ *                        id), order[i] = position of slot perm[i] in ge_hinge_grad's output
+ *   ge_plan_item_counts  per run: ceil(length / max_item) items, and whether it is split (n_runs: device scalar U;
+ *                        entries in [U, cap) are zeroed so that scans over the capacity are exact)
+ *   ge_plan_items        per run, at it_incl[u] - n_it[u]: begin / length of each item in the sorted order and its
+ *                        destination row (row_of[u], or u minus its step's first run when row_of is NULL:
+ *                        step = bucket[u] / G), ~row for split runs, whose rows are listed in split_rows
+ * Everything is bit-exact integer work; tests compare with the tensor-op planner word for word. */
+int ge_plan_keys(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int64_t G, void* key_out,
+                 int key64, void* stream);
+int ge_plan_flags(const void* key_sorted, int64_t n, int key64, int32_t* flag_out, void* stream);
+int ge_plan_heads(const void* key_sorted, const int32_t* incl, int64_t n, int key64, int64_t div, int32_t* first_pos,
+                  int32_t* quot, int32_t* rem, void* stream);
+int ge_plan_scatter(const int64_t* perm, const int32_t* incl, const int64_t* step_start, const int32_t* pos,
+                    const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t* remap, int32_t* order, void* stream);
+int ge_plan_item_counts(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, int32_t max_item, int32_t* n_it,
+                        int32_t* split, void* stream);
+int ge_plan_items(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, const int64_t* it_incl,
+                  const int64_t* sp_incl, const int32_t* row_of, const int32_t* bucket, const int64_t* step_start,
+                  int64_t G, int32_t max_item, int32_t* begin, int32_t* length, int32_t* target, int64_t* split_rows,
+                  void* stream);
+
 /* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
  * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already
  * shuffled [T,3] int32 array, wrapping to row 0 when the next batch would run past T -- the

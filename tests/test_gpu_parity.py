@@ -442,6 +442,55 @@ def test_sharded_trainer_single_rank_uses_hip_kernels(H, shape):
     assert np.abs(a.cpu().numpy() - ctab).max() < 2e-5
 
 
+def _plans_equal(p, q):
+    assert (p.S, p.B, p.sc, p.rc, p.req_start, p.unique_rows, p.remote_rows) == (q.S, q.B, q.sc, q.rc, q.req_start, q.unique_rows, q.remote_rows)
+    assert torch.equal(p.remap, q.remap) and torch.equal(p.req_all, q.req_all)
+    for a, b in ((p.reduce_items, q.reduce_items), (p.apply_items, q.apply_items)):
+        assert a.item_start == b.item_start and a.split_start == b.split_start
+        for f in ("order", "begin", "length", "target", "split_rows"):
+            x, y = getattr(a, f), getattr(b, f)
+            assert x.dtype == y.dtype and torch.equal(x, y), f
+
+
+@pytest.mark.parametrize("shape", ["fb15k", "config4", "hot"])
+def test_native_exchange_planner_equals_tensor_op_planner(H, shape):
+    """ge_plan_* (csrc/ge_plan.hip) vs the tensor-op planner of sharded.py on the same chunk: every field of the plan
+    word for word -- staging order, slot remap, request lists, and the work items of both reductions (incl. rows
+    split over several items: 'hot' puts 5000 slots on one row), with ids outside the table."""
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import sharded as S
+    if shape == "config4":
+        S_, B = 3, 16384
+        data, pos_h = D.synthetic_large(n_entities=1_200_000, n_triples=S_ * B, seed=77)
+        names, id_to_type, offsets, ids = D.synthetic_large_type_arrays(data)
+        n_rows = data.entity_count
+    else:
+        S_, B = 4, 2048
+        fb = D.fb15k_shape()
+        names, id_to_type, offsets, ids = fb.type_arrays()
+        pos_h = D.synthetic_fb15k_triples(fb, n_triples=S_ * B, seed=5)
+        n_rows = fb.entity_count
+        if shape == "hot":
+            pos_h[:5000, 0] = fb.relation_count + 17
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    shard = torch.zeros(n_rows, 8, device="cuda")
+    tr = S.ShardedTrainer(shard, n_rows, tt, seed=4)
+    pos = dev(pos_h).view(S_, B, 3)
+    neg = tr.sample_negatives(pos).to(torch.int32)
+    pos = pos.clone()
+    pos[1, 5, 0] = -3                                   # invalid ids: their slots stay empty
+    pos[2, 9, 1] = n_rows + 11
+    assert tr.k.native_planner
+    native = tr.plan_chunk(pos, neg)
+    tr.k.native_planner = False
+    try:
+        ref = tr.plan_chunk(pos, neg)
+    finally:
+        tr.k.native_planner = True
+    _plans_equal(native, ref)
+    assert shape != "hot" or len(native.reduce_items.split_rows) > 0
+
+
 # ---------------------------------------------------------------- native training loop (ge_train_steps)
 @pytest.mark.parametrize("model,B,d,steps", [("complex", 1024, 200, 70), ("complex", 4096, 200, 6),
                                              ("complex", 100, 50, 9), ("hole", 256, 64, 5), ("hole_direct", 256, 64, 5),

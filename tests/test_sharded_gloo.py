@@ -103,7 +103,12 @@ def _worker(rank, world, port, q):
         # two pipelined chunks of one step each (the second chunk's plan is built right after the first
         # chunk's steps are issued, on its own process group), then a single step: updates of earlier
         # steps must be visible to later fetches
-        l01 = tr.run_pipelined([mine[None], mine[None]], lambda gs: 0.05)
+        # ... the first through a plan that an (empty) earlier call built as its look-ahead, the second call's
+        # own look-ahead is never adopted (the single step that follows passes other positives) and must be harmless
+        first = mine[None].to(torch.int32).contiguous()
+        assert tr.run_pipelined([], lambda gs: 0.05, lookahead=first) is None and tr._pending is not None
+        l01 = tr.run_pipelined([first, mine[None]], lambda gs: 0.05, lookahead=first)
+        assert tr._pending is not None and tr._pending[1] == 2
         losses = [l01[0], l01[1], tr.step(mine, lr=0.05)]
         out = tr.gather_full_table()
         mean = tr.mean_loss(losses[-1])
