@@ -103,7 +103,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and the header diverge
             fn.restype = res
             fn.argtypes = args
-        if lib.ge_version() < 200:
+        if lib.ge_version() < 210:
             raise RuntimeError("libge_hip.so is older than the Python host expects")
         _lib = lib
     return _lib

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE_VERSION 200 /* 0.2.0 */
+#define GE_VERSION 210 /* 0.2.1: ge_rank_1vK (model), ge_plan_* */
 
 /* argument errors (negative, -errno style) */
 #define GE_EINVAL (-22)  /* bad dimension / null pointer / misaligned buffer */
