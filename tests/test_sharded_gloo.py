@@ -6,6 +6,7 @@ here by an oracle-backed double (tests may use the oracle; the product default i
 raises without a GPU).  Correctness oracle = the single-process result on the same global batch.
 """
 import os
+import time
 import socket
 from types import SimpleNamespace
 
@@ -127,10 +128,23 @@ def test_sharded_step_equals_single_process_result(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got_table, got_losses, mean, uniq = q.get()
+    deadline, msg = time.time() + 240, None
+    while time.time() < deadline:                    # never block on a worker that died before q.put
+        if not q.empty():
+            msg = q.get()
+            break
+        if not any(p.is_alive() for p in procs):
+            break
+        time.sleep(0.1)
+    if msg is None and not q.empty():
+        msg = q.get()
     for p in procs:
         p.join(60)
-        assert p.exitcode == 0
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
+    assert all(p.exitcode == 0 for p in procs)
+    got_table, got_losses, mean, uniq = msg
     # single-process reference on the same global batches, same sampler streams
     table, id_to_type, offsets, type_ids, pos = _problem()
     B = len(pos)
