@@ -5,20 +5,24 @@
 // wave per SIMD (the Q operand fills the LDS, so a CU holds one workgroup):
 //   * LDS reads, LDS writes and global loads issued BETWEEN matrix instructions are free (2-3 cycles each);
 //   * operand reads issued up front are not (+8 % per 64-MFMA chunk), a workgroup barrier costs ~5 %;
-//   * every VALU instruction costs ~3.7 cycles of matrix-pipe time wherever it is placed.
+//   * VALU instructions never hide behind the matrix pipe: 2.3 (bursts) to 4.9 (spread out) cycles of MFMA time
+//     each in the probe, more in the kernel when they chain through scalar registers.
 // So the kernel is organised around the MFMA stream and nothing else may take VALU slots:
 //   * the candidate chunk width CW divides embedding_dim (40 for d = 200: 5 chunks, no tail, no masking);
 //   * operands travel LDS -> registers in groups of 4 k-pairs (16 MFMAs); group g+1 is read between the MFMAs
 //     of group g, into the other of two 16-register sets, across chunk boundaries too;
 //   * candidate rows travel global -> registers (chunk q+2) -> LDS (chunk q+1) between the MFMAs of chunk q;
 //     addresses advance by immediates, requests are never predicated (a branch makes the waitcnt pass serialise
-//     them), the one barrier per chunk sits before the chunk's last operand group;
+//     them), the one barrier per chunk sits before the chunk's last operand group; the row norm is two FMA chains;
 //   * the epilogue compares RAW scores: per test row two thresholds lo/hi bracket the true candidate's score by
-//     more than the sigmoid's rounding, x < lo means "pops before", x > hi "pops after"; only a 32 x 32 block
-//     with an element inside a bracket (a few per thousand) recomputes the exact fp32 sigmoid comparison with
-//     the id tie-break.  The outcome equals comparing the sigmoids everywhere; the common path is a multiply,
-//     two compares and two v_writelane per score;
-//   * the grid is two workgroups per CU, each with an equal share of the (row block x candidate tile) list.
+//     more than the sigmoid's rounding, x < lo means "pops before", x > hi "pops after".  Per score: a multiply,
+//     two compares, two v_writelane (the "before" bit into the row-major mask) and two v_addc (both outcomes
+//     into per-lane bitmaps).  Where the bitmaps differ the score sits inside a bracket: only those lanes
+//     evaluate the exact fp32 sigmoid comparison with the id tie-break and set the bit in LDS.  The outcome
+//     equals comparing the sigmoids everywhere;
+//   * the grid is two workgroups per CU, each with an equal share of the (row block x candidate tile) list;
+//   * model: ComplEx, or HolE on a table held in the frequency domain (same GEMM; Hermitian weights go into Q,
+//     the candidate norm is Parseval-weighted).
 #include <algorithm>
 #include <type_traits>
 
