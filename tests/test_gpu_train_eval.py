@@ -151,6 +151,58 @@ def test_hole_ranks_from_the_spectral_sweep(d):
         E.link_prediction_ranks(emb, test, cand, known, model="hole", fused=False)
 
 
+@pytest.mark.parametrize("d", [40, 56])
+def test_rank_sweep_edge_shapes_and_bad_ids(d):
+    """One row / one candidate, sizes one past the 128-wide tiles, a max_norm below every row norm, ids outside the
+    table: a bad (fixed, relation) row or true id ranks nothing before it, a bad candidate is never counted, nothing
+    faults (pipelined kernel at d = 40, generic at 56)."""
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(11)
+    N = 300
+    table = (rng.standard_normal((N, d)) * 0.3).astype(np.float32)
+    emb = torch.as_tensor(table).cuda()
+
+    def heap_counts(scores, cand_ids, tid):
+        out = []
+        for i in range(scores.shape[0]):
+            st = scores[i, list(cand_ids).index(tid[i])]
+            out.append(int(((scores[i] < st) | ((scores[i] == st) & (np.asarray(cand_ids) < tid[i]))).sum()))
+        return out
+
+    for B, K, mn in ((1, 1, 1.0), (129, 257, 1.0), (5, 130, 0.5)):
+        cand = rng.permutation(np.arange(4, N))[:K].astype(np.int32)
+        hr = np.stack([rng.integers(4, N, B), rng.integers(0, 4, B)], 1).astype(np.int32)
+        tid = cand[rng.integers(0, K, B)].astype(np.int32)
+        for head in (False, True):
+            nb, nk, sc = H.rank_candidates(emb, torch.as_tensor(hr).cuda(), torch.as_tensor(tid).cuda(),
+                                           torch.as_tensor(cand).cuda(), cand_is_head=head, max_norm=mn, return_scores=True)
+            nb2, _ = H.rank_candidates(emb, torch.as_tensor(hr).cuda(), torch.as_tensor(tid).cuda(),
+                                       torch.as_tensor(cand).cuda(), cand_is_head=head, max_norm=mn)
+            exp = heap_counts(sc.cpu().numpy(), cand, tid)
+            assert nb.cpu().tolist() == exp and nb2.cpu().tolist() == exp and int(nk.abs().sum()) == 0
+    # ids outside the table
+    B, K = 130, 200
+    cand = np.arange(4, 4 + K).astype(np.int32)
+    hr = np.stack([rng.integers(4, N, B), rng.integers(0, 4, B)], 1).astype(np.int32)
+    tid = cand[rng.integers(0, K, B)].astype(np.int32)
+    good = H.rank_candidates(emb, torch.as_tensor(hr).cuda(), torch.as_tensor(tid).cuda(), torch.as_tensor(cand).cuda())[0].cpu().numpy()
+    hr_b, tid_b, cand_b = hr.copy(), tid.copy(), cand.copy()
+    hr_b[3, 0] = N + 5
+    hr_b[64, 1] = -1
+    tid_b[7] = -2
+    cand_b[10] = N + 100                                 # never counted; rows whose true id it was are excluded below
+    got = H.rank_candidates(emb, torch.as_tensor(hr_b).cuda(), torch.as_tensor(tid_b).cuda(), torch.as_tensor(cand_b).cuda())[0].cpu().numpy()
+    assert got[3] == 0 and got[64] == 0 and got[7] == 0
+    sc = H.rank_candidates(emb, torch.as_tensor(hr).cuda(), torch.as_tensor(tid).cuda(), torch.as_tensor(cand).cuda(),
+                           return_scores=True)[2].cpu().numpy()
+    for i in range(B):
+        if i in (3, 64, 7) or tid[i] == cand[10]:
+            continue
+        st = sc[i, tid[i] - 4]
+        before_bad = (sc[i, 10] < st) or (sc[i, 10] == st and cand[10] < tid[i])
+        assert got[i] == good[i] - int(before_bad)
+
+
 def test_fused_and_unfused_rankers_agree_at_fb15k_scale():
     """Full-width sweep (14,951 candidates, 117 column tiles, d = 200): the epilogue-counted ranks and the
     ranks from stored scores differ only where two candidates' losses are within a few ulps of each other in one
