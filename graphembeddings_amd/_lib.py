@@ -45,6 +45,9 @@ SYMBOLS = {
     "ge_plan_scatter": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "ge_plan_item_counts": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "ge_plan_items": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "ge_validation_workspace_bytes": (C.c_size_t, [_i64]),
+    "ge_validation_tick": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _i32, _p, C.c_uint64, C.c_uint64, _i32, _i32,
+                                      _f, _f, C.c_int, _p, C.c_size_t, _p, _p, _p, _p]),
     "ge_rank_max_dim": (C.c_int, []),
     "ge_complex_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "ge_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p]),

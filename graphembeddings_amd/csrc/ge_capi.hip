@@ -14,6 +14,9 @@ int plan_heads_launch(const void*, const int32_t*, int64_t, int, int64_t, int32_
 int plan_scatter_launch(const int64_t*, const int32_t*, const int64_t*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, hipStream_t);
 int plan_item_counts_launch(const int32_t*, const int32_t*, int64_t, int32_t, int32_t*, int32_t*, hipStream_t);
 int plan_items_launch(const int32_t*, const int32_t*, int64_t, const int64_t*, const int64_t*, const int32_t*, const int32_t*, const int64_t*, int64_t, int32_t, int32_t*, int32_t*, int32_t*, int64_t*, hipStream_t);
+int select_rows_launch(const int32_t*, int64_t, int64_t, uint64_t, uint64_t, int32_t*, hipStream_t);
+int mean_pocket_launch(const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+int copy_if_launch(const float*, float*, int64_t, const int32_t*, hipStream_t);
 int rank_max_dim();
 int complex_rank_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float, int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, hipStream_t);
 int hole_spectral_launch(float*, int64_t, int32_t, int, hipStream_t);
@@ -51,6 +54,10 @@ static inline bool max_norm_ok(float m) { return m > 0.f; }
 extern "C" {
 
 int ge_version(void) { return GE_VERSION; }
+
+size_t ge_validation_workspace_bytes(int64_t B) {
+  return B <= 0 ? 0 : ((size_t)B * (3 + 3 + 1) * 4 + 16 + 255) / 256 * 256;
+}
 
 int ge_max_dim(void) { return complex_max_dim(); }
 
@@ -106,6 +113,31 @@ int ge_hinge_loss(const float* table, int64_t N, int32_t d, const int32_t* pos, 
     return complex_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream,
                                      model == GE_MODEL_HOLE_SPECTRAL);
   return hole_hinge_loss_launch(table, N, d, pos, neg, B, margin, max_norm, loss, sig_out, (hipStream_t)stream);
+}
+
+int ge_validation_tick(const float* table, int64_t N, int32_t d, const int32_t* valid, int64_t V, int64_t B,
+                       const int32_t* id_to_type, const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,
+                       uint64_t seed, uint64_t counter, int32_t padded_size, int32_t mode, float margin, float max_norm,
+                       int model, void* workspace, size_t workspace_bytes, float* mean_out, float* best, float* pocket,
+                       void* stream) {
+  if (B <= 0 || V <= 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm) || model < 0 || model > 2) return GE_EINVAL;
+  if (!valid || !id_to_type || !type_offsets || !type_ids || !workspace || !mean_out || !best) return GE_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return GE_EINVAL;
+  if (workspace_bytes < ge_validation_workspace_bytes(B)) return GE_ENOMEM;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* pos = (int32_t*)workspace;                 // [B,3] | neg [B,3] | loss [B] | flag
+  int32_t* neg = pos + 3 * B;
+  float* loss = (float*)(neg + 3 * B);
+  int32_t* flag = (int32_t*)(loss + B);
+  int rc = select_rows_launch(valid, V, B, seed, counter, pos, st);
+  if (rc) return rc;
+  rc = corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, counter, padded_size, mode, neg, st);
+  if (rc) return rc;
+  rc = ge_hinge_loss(table, N, d, pos, neg, B, margin, max_norm, model, loss, nullptr, stream);
+  if (rc) return rc;
+  rc = mean_pocket_launch(loss, B, mean_out, best, flag, st);
+  if (rc || !pocket) return rc;
+  return copy_if_launch(table, pocket, N * (int64_t)d, flag, st);
 }
 
 int ge_hinge_grad(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,

@@ -280,4 +280,82 @@ int corrupt_batch_launch(const int32_t* pos, int64_t B, const int32_t* id_to_typ
   return launch_status();
 }
 
+// ---------------------------------------------------------------- validation tick (holE.py:299-304, 351-360)
+#define GE_TAG_VSEL 0x7673656Cu
+
+// a batch of validation triples drawn uniformly with replacement (the reference takes them from a shuffle queue
+// over the validation split, holE.py:300): out[i] = valid[philox(seed, counter, i) % V]
+__global__ __launch_bounds__(kBlock) void select_rows_kernel(const int32_t* __restrict__ valid, int64_t V, int64_t B,
+                                                             uint64_t seed, uint64_t counter, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B) return;
+  const uint32_t w0 = philox_w0((uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)i, (uint32_t)(i >> 32),
+                                (uint32_t)seed ^ GE_TAG_VSEL, (uint32_t)(seed >> 32));
+  const uint32_t w1 = philox_w0((uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)i, (uint32_t)(i >> 32) ^ 0x80000000u,
+                                (uint32_t)seed ^ GE_TAG_VSEL, (uint32_t)(seed >> 32));
+  const uint64_t r = (((uint64_t)w1 << 32) | w0) % (uint64_t)V;
+  out[3 * i] = valid[3 * r];
+  out[3 * i + 1] = valid[3 * r + 1];
+  out[3 * i + 2] = valid[3 * r + 2];
+}
+
+// one workgroup: mean of the loss vector (fixed summation order: bitwise reproducible) -> *mean_out; the pocket
+// bookkeeping of holE.py:357-360 on the device: improved = mean < *best, *best = min, *flag = improved
+__global__ __launch_bounds__(1024) void mean_pocket_kernel(const float* __restrict__ loss, int64_t B,
+                                                           float* __restrict__ mean_out, float* __restrict__ best,
+                                                           int32_t* __restrict__ flag) {
+  __shared__ double part[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += 1024) s += (double)loss[i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, kWave);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    const float mean = (float)(t / (double)B);
+    *mean_out = mean;
+    const bool improved = mean < *best;     // a NaN loss never improves
+    if (improved) *best = mean;
+    *flag = improved ? 1 : 0;
+  }
+}
+
+// pocket <- table iff *flag (the flag is read on the device: no host decision, no synchronisation)
+__global__ __launch_bounds__(kBlock) void copy_if_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                         int64_t n4, const float* __restrict__ src_tail,
+                                                         float* __restrict__ dst_tail, int n_tail,
+                                                         const int32_t* __restrict__ flag) {
+  if (*flag == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+int select_rows_launch(const int32_t* valid, int64_t V, int64_t B, uint64_t seed, uint64_t counter, int32_t* out,
+                       hipStream_t st) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for(B, kBlock)), dim3(kBlock), 0, st, valid, V, B, seed, counter, out);
+  return launch_status();
+}
+
+int mean_pocket_launch(const float* loss, int64_t B, float* mean_out, float* best, int32_t* flag, hipStream_t st) {
+  hipLaunchKernelGGL(mean_pocket_kernel, dim3(1), dim3(1024), 0, st, loss, B, mean_out, best, flag);
+  return launch_status();
+}
+
+int copy_if_launch(const float* src, float* dst, int64_t n, const int32_t* flag, hipStream_t st) {
+  if (n == 0) return 0;
+  const bool vec = reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  const int64_t rest = n - 4 * n4;
+  if (rest > kBlock) {   // unaligned buffers: plain float copy through the tail path is not enough; fall back to scalars
+    return GE_EINVAL;
+  }
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + kBlock - 1) / kBlock, 256 * 8));
+  hipLaunchKernelGGL(copy_if_kernel, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), n4, src + 4 * n4, dst + 4 * n4, (int)rest, flag);
+  return launch_status();
+}
+
 }  // namespace ge

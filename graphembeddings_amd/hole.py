@@ -393,6 +393,52 @@ def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, 
     return out
 
 
+class ValidationPocket:
+    """The validation ticks of the training loop (holE.py:299-304, 351-360) without a host round trip per tick
+    (ge_validation_tick): each tick draws a validation batch on the device, corrupts it, takes the mean hinge into
+    `hist`, and -- the reference's "pocket" -- copies the table into `pocket` iff that mean is the best so far.
+    The host calls read() when it wants the numbers (one synchronisation for all ticks since the last read)."""
+
+    def __init__(self, embeddings: torch.Tensor, validation_triples: torch.Tensor, type_tables: "TypeTables",
+                 batch_size: int, *, margin: float = 0.2, model="complex", max_norm: float = 1.0, seed: int = 0,
+                 mode: int = CORRUPT_BATCH_COIN, keep_table: bool = True, capacity: int = 4096):
+        self.emb = _table(embeddings)
+        _need_cuda(validation_triples, "validation_triples")
+        self.valid = validation_triples.to(torch.int32).contiguous()
+        if self.valid.dim() != 2 or self.valid.shape[1] != 3 or self.valid.shape[0] == 0:
+            raise ValueError("validation_triples must be [V,3] with V > 0")
+        self.tt, self.B = type_tables, int(batch_size)
+        self.margin, self.max_norm, self.model = float(margin), float(max_norm), _MODELS[model]
+        self.seed, self.mode = int(seed), int(mode)
+        dev = self.emb.device
+        self.best = torch.full((), 2.0, dtype=torch.float32, device=dev)     # holE.py:336 pocket_loss = 2.
+        self.pocket = torch.empty_like(self.emb) if keep_table else None
+        self.hist = torch.zeros(int(capacity), dtype=torch.float32, device=dev)
+        self._ws = torch.empty(max(_lib.load().ge_validation_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)
+        self._steps = []        # global step of each tick since the last read()
+
+    def tick(self, counter: int, global_step: int) -> None:
+        if len(self._steps) >= self.hist.numel():
+            raise RuntimeError("ValidationPocket: read() the pending ticks first (capacity %d)" % self.hist.numel())
+        tt, i = self.tt, len(self._steps)
+        _lib.call("ge_validation_tick", self.emb.data_ptr(), self.emb.shape[0], self.emb.shape[1], self.valid.data_ptr(),
+                  self.valid.shape[0], self.B, tt.id_to_type.data_ptr(), tt.type_offsets.data_ptr(), tt.n_types,
+                  tt.type_ids.data_ptr(), self.seed & (2**64 - 1), int(counter) & (2**64 - 1), tt.padded_size, self.mode, self.margin, self.max_norm,
+                  self.model, self._ws.data_ptr(), self._ws.numel(), self.hist.data_ptr() + 4 * i, self.best.data_ptr(),
+                  self.pocket.data_ptr() if self.pocket is not None else None, _stream())
+        self._steps.append(int(global_step))
+
+    def read(self):
+        """[(global_step, mean validation hinge)] of the ticks since the last read, in order (synchronises)."""
+        n = len(self._steps)
+        if n == 0:
+            return []
+        vals = self.hist[:n].cpu().tolist()
+        out = list(zip(self._steps, vals))
+        self._steps = []
+        return out
+
+
 def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
     _need_cuda(t, name)
     if t.dtype != torch.int32 or not t.is_contiguous():

@@ -87,6 +87,20 @@ int ge_hinge_loss(const float* table, int64_t N, int32_t d, const int32_t* pos, 
                   int64_t B, float margin, float max_norm, int model, float* loss, float* sig_out,
                   void* stream);
 
+/* --- one validation tick of the training loop (holE.py:299-304, 351-360), enqueued without any host decision:
+ * a batch of B triples drawn uniformly (with replacement, Philox keyed by (seed, counter)) from the device-resident
+ * validation split valid [V,3]; type-safe negatives (ge_corrupt_batch with step = counter); the hinge of
+ * ge_hinge_loss; its mean -> *mean_out (device); and the reference's "pocket": if the mean is below *best (device
+ * scalar, start it at 2.0 as holE.py:336 does) then *best = mean and, when pocket is not NULL, pocket <- table.
+ * The host reads the means whenever it likes (e.g. once per epoch) and knows from them which tick the pocket
+ * holds.  workspace: >= ge_validation_workspace_bytes(B), 16-byte aligned. */
+size_t ge_validation_workspace_bytes(int64_t B);
+int ge_validation_tick(const float* table, int64_t N, int32_t d, const int32_t* valid, int64_t V, int64_t B,
+                       const int32_t* id_to_type, const int64_t* type_offsets, int32_t n_types, const int32_t* type_ids,
+                       uint64_t seed, uint64_t counter, int32_t padded_size, int32_t mode, float margin, float max_norm,
+                       int model, void* workspace, size_t workspace_bytes, float* mean_out, float* best, float* pocket,
+                       void* stream);
+
 /* --- one SGD step of holE.py:296 on the hinge of holE.py:231: forward of both sides, gradient of
  * SUM_i loss_i through sigmoid, score and the clip, then table[row] -= lr * grad for every
  * occurrence (ScatterSub semantics, duplicates accumulate; holE-20170724/graph.pbtxt:47850-48001).

@@ -491,6 +491,47 @@ def test_native_exchange_planner_equals_tensor_op_planner(H, shape):
     assert shape != "hot" or len(native.reduce_items.split_rows) > 0
 
 
+def test_validation_tick_matches_oracle_and_keeps_the_best_table(H):
+    """ge_validation_tick (hole.ValidationPocket): the batch it draws (Philox, restated here), its negatives and mean
+    hinge equal the oracle's on the same rows; the pocket takes the table exactly when the mean improves."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    table_h = O.init_table(fb.entity_count, 64, seed=3) * 8.0
+    emb = dev(table_h)
+    valid_h = fb.validation_triples[:5000].astype(np.int32)
+    B, seed = 512, 0xABCDEF0123
+    vp = H.ValidationPocket(emb, dev(valid_h), tt, B, margin=0.2, seed=seed)
+
+    def expect(counter, tab):
+        i = np.arange(B, dtype=np.uint64)
+        lo, hi = i & np.uint64(0xFFFFFFFF), i >> np.uint64(32)
+        k0, k1 = (seed & 0xFFFFFFFF) ^ 0x7673656C, (seed >> 32) & 0xFFFFFFFF
+        w0 = O.philox4x32_10(counter & 0xFFFFFFFF, counter >> 32, lo, hi, k0, k1)[0].astype(np.uint64)
+        w1 = O.philox4x32_10(counter & 0xFFFFFFFF, counter >> 32, lo, hi ^ np.uint64(0x80000000), k0, k1)[0].astype(np.uint64)
+        rows = ((w1 << np.uint64(32)) | w0) % np.uint64(len(valid_h))
+        pos = valid_h[rows.astype(np.int64)]
+        neg = O.corrupt_batch(pos, id_to_type, offsets, ids, seed, counter, 1024, 0)
+        return float(O.evaluate_batch(pos, neg, tab.astype(np.float64), 0.2).mean())
+
+    vp.tick(7, 100)
+    first = emb.clone()
+    emb.mul_(0.5)                                     # another table: its mean hinge differs
+    vp.tick(8, 107)
+    second = emb.clone()
+    emb.zero_()                                       # all scores 0: mean hinge = margin, worse than a trained-ish table? checked below
+    vp.tick(9, 114)
+    got = vp.read()
+    exp = [expect(7, table_h), expect(8, table_h * np.float32(0.5)), expect(9, np.zeros_like(table_h))]
+    assert [g[0] for g in got] == [100, 107, 114]
+    assert np.abs(np.array([g[1] for g in got]) - np.array(exp)).max() < 1e-5
+    best = int(np.argmin([g[1] for g in got]))
+    want = [first, second, emb][best]
+    assert torch.equal(vp.pocket, want) and abs(float(vp.best) - got[best][1]) == 0.0
+    assert vp.read() == []
+
+
 # ---------------------------------------------------------------- native training loop (ge_train_steps)
 @pytest.mark.parametrize("model,B,d,steps", [("complex", 1024, 200, 70), ("complex", 4096, 200, 6),
                                              ("complex", 100, 50, 9), ("hole", 256, 64, 5), ("hole_direct", 256, 64, 5),
