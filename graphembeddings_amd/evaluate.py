@@ -74,7 +74,7 @@ class KnownIndex:
 
 @torch.no_grad()
 def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, candidates: np.ndarray,
-                          known_triples: np.ndarray = None, side: str = "tail", batch: int = 16384,
+                          known_triples: np.ndarray = None, side: str = "tail", batch: int = None,
                           max_norm: float = 1.0, fused: bool = None, model: str = "complex"):
     """Raw and filtered rank of every test triple's true entity among `candidates`, with the
     semantics of holE.py:446-469.  side="tail": candidates replace the tail; "head": the head.
@@ -106,6 +106,10 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
     pos_of = torch.full((embeddings.shape[0],), -1, dtype=torch.int64, device=dev)
     pos_of[cand64] = torch.arange(cand.numel(), device=dev)
     index = KnownIndex(known_triples, embeddings.shape[0], side, dev)
+    if batch is None:
+        # test rows per call: the stored-scores path holds a [batch, K] fp32 matrix; the fused sweep holds nothing
+        # per row, and longer calls amortise its per-row-block set-up (the whole FB15k test set is one call)
+        batch = 1 << 17 if fused else 16384
     raw_all, fil_all = [], []
     fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
     for s in range(0, len(test), batch):
@@ -142,7 +146,7 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
     return np.concatenate(raw_all), np.concatenate(fil_all)
 
 
-def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True, batch: int = 16384,
+def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True, batch: int = None,
                          verbose: bool = True, model: str = "complex") -> dict:
     """Filtered link prediction over all entities (rows >= relation_count) for
     data.test_array, filtering train+valid triples as the reference does (holE.py:413-422)."""
