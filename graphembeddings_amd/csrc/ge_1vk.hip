@@ -13,6 +13,7 @@
 // wave TM x TN tiles of 32x32; k is walked in chunks of 16 complex dims (= 32 real k) staged in LDS
 // with a row stride of 33 floats so the 32 rows a half-wave reads per operand fall in 32 banks.
 #include "ge_common.h"
+#include "ge_rank_dev.h"
 
 namespace ge {
 
@@ -309,6 +310,12 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
                              int cand_is_head, float* out, hipStream_t st) {
   if (d <= 0 || (d & 1)) return GE_EINVAL;
   if (B == 0 || K == 0) return 0;
+  // large sweeps with embedding_dim a multiple of 40 / 32 / 24: the software-pipelined kernel of ge_rank_pipe.hip
+  // (Q resident in LDS, operands and candidate rows issued between the MFMAs) writing scores instead of counting
+  if (((B + 127) / 128) * ((K + 127) / 128) >= 512 && reinterpret_cast<uintptr_t>(table) % 16 == 0) {
+    const int rc = score_pipe_launch(table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out, st);
+    if (rc != GE_ENOTSUP) return rc;
+  }
   const int k = d / 2;
   const bool v4 = (k % 4 == 0) && (reinterpret_cast<uintptr_t>(table) % 16 == 0);
   const int64_t big_blocks = ((B + 127) / 128) * ((K + 127) / 128);

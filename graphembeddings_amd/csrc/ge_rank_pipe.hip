@@ -244,13 +244,16 @@ __device__ __forceinline__ void exact_masks(const PipeLds& lds, float x0, float 
   }
 }
 
-template <int CW, int NCH, bool SCORES>
+// MODE 0: ranks.  1: ranks, every loss computed exactly and stored too (tests).  2: no ranking at all -- the sweep
+// writes scores_out[B,K] (raw score, or its sigmoid when `sweep_flags` & 1): ge_complex_score_1vK on this pipeline.
+template <int CW, int NCH, int MODE>
 __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
     int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
-    float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec) {
+    float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags) {
+  constexpr bool SCORES = MODE == 1;
   using C = Cfg<CW>;
   constexpr int NV = C::kNV;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("")
                                        : clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d;
         lds.skip[srow] = 0;
-        lds.tI[srow] = r < B ? true_id[r] : -1;
+        lds.tI[srow] = (MODE != 2 && r < B) ? true_id[r] : -1;
       }
     }
     __syncthreads();
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     f32x16 acc[2][2];
     float4 rA[NV], rB[NV];
     // ---- the true candidates: a tile whose candidate rows are this block's 128 true entities
-    {
+    if constexpr (MODE != 2) {
       const int32_t tid = lds.tI[srow];
       pipe_fetch<CW>(table, N, d, tid, 0, rA);
       pipe_fetch<CW>(table, N, d, tid, 1, rB);
@@ -398,6 +401,24 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       // A candidate beyond K or with a bad id has a NaN clip scale, a row beyond B a NaN bracket: no bit is set.
       const int cl0 = wn * 64 + li, cl1 = cl0 + 32;
       const float sb0 = lds.sB[cl0], sb1 = lds.sB[cl1];
+      if constexpr (MODE == 2) {                                 // scores only: 32 consecutive floats of a row per half-wave
+        const int64_t col0 = n0 + cl0, col1 = n0 + cl1;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            const int64_t row = m0 + rl;
+            const float sa = lds.sA[rl];
+            float v0 = acc[tm][0][q] * sb0 * sa, v1 = acc[tm][1][q] * sb1 * sa;
+            if (sweep_flags & 1) { v0 = rank_sigmoid(v0); v1 = rank_sigmoid(v1); }   // 4 VALU, within 3e-7 of expf's
+            if (row < B) {
+              if (col0 < K) scores_out[row * K + col0] = v0;
+              if (col1 < K) scores_out[row * K + col1] = v1;
+            }
+          }
+        continue;
+      }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
         int M0 = 0, M1 = 0;                                      // lane r: the 32 column bits of row r of the 32 x 32 block
@@ -475,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       // no barrier: the next tile's first write to bm / sB comes after its own barriers
     }
     __syncthreads();
-    if (t < kRB && m0 + t < B) {
+    if (MODE != 2 && t < kRB && m0 + t < B) {
       if (raw_reg) atomicAdd(&raw_cnt[m0 + t], raw_reg);
       if (lds.skip[t]) atomicAdd(&skip_cnt[m0 + t], lds.skip[t]);
     }
@@ -493,7 +514,7 @@ template <int CW>
 int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                    const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                    const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss, float* scores_out,
-                   int spec, hipStream_t st) {
+                   int spec, int scores_only, int sweep_flags, hipStream_t st) {
   const size_t lds = pipe_lds_bytes<CW>(d);
   if (lds > 160 * 1024) return GE_ENOTSUP;
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
@@ -505,23 +526,42 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds, st, table, N, d, hr, B, true_id, cand, K, max_norm,
-                       cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec);
+                       cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec, sweep_flags);
     return launch_status();
   };
-  if (scores_out) return go(rank_pipe_kernel<CW, 0, true>);
-  if (CW == 40 && d == 200) return go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), false>);   // the FB15k configuration, unrolled
-  return go(rank_pipe_kernel<CW, 0, false>);
+  if (scores_only) return (CW == 40 && d == 200) ? go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 2>) : go(rank_pipe_kernel<CW, 0, 2>);
+  if (scores_out) return go(rank_pipe_kernel<CW, 0, 1>);
+  if (CW == 40 && d == 200) return go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 0>);   // the FB15k configuration, unrolled
+  return go(rank_pipe_kernel<CW, 0, 0>);
 }
 
 }  // namespace
+
+int sweep_pipe_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float,
+                      int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, int, int, hipStream_t);
 
 int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                      float* scores_out, int spec, hipStream_t st) {
+  return sweep_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
+                           skip_cnt, true_loss, scores_out, spec, 0, 0, st);
+}
+
+// ge_complex_score_1vK on the same pipeline: out [B,K] = score (sigmoid when apply_sigmoid)
+int score_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* cand,
+                      int64_t K, float max_norm, int apply_sigmoid, int cand_is_head, float* out, hipStream_t st) {
+  return sweep_pipe_launch(table, N, d, hr, B, nullptr, cand, K, max_norm, cand_is_head, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, out, 0, 1, apply_sigmoid ? 1 : 0, st);
+}
+
+int sweep_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
+                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
+                      float* scores_out, int spec, int scores_only, int sweep_flags, hipStream_t st) {
 #define GE_PIPE(CW)                                                                                                  \
   return pipe_launch_cw<CW>(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt, \
-                            skip_cnt, true_loss, scores_out, spec, st)
+                            skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, st)
   if (d % 40 == 0) GE_PIPE(40);
   if (d % 32 == 0) GE_PIPE(32);
   if (d % 24 == 0) GE_PIPE(24);
