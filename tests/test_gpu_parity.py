@@ -442,6 +442,49 @@ def test_sharded_trainer_single_rank_uses_hip_kernels(H, shape):
     assert np.abs(a.cpu().numpy() - ctab).max() < 2e-5
 
 
+@pytest.mark.parametrize("model", ["hole", "hole_spectral"])
+def test_sharded_trainer_hole_models_equal_the_plain_step(H, model):
+    """The row-sharded step with the HolE score (real table: direct correlation; spectral table: the ComplEx-shaped
+    form) at world size 1 equals the plain fused step of the same model on the same negatives."""
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import sharded as S
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    d, B = 64, 1024
+    table = dev(O.init_table(fb.entity_count, d, seed=6) * 6.0)
+    if model == "hole_spectral":
+        H.hole_to_spectral(table)
+    pos = dev(D.synthetic_fb15k_triples(fb, n_triples=B, seed=8))
+    a = table.clone()
+    tr = S.ShardedTrainer(a, fb.entity_count, tt, seed=4, model=model)
+    loss_s = tr.step(pos, lr=0.1)
+    neg = H.corrupt_batch(tt, fb.relation_count, pos, seed=4, step=0)
+    b = table.clone()
+    loss_p = H.HingeSGD(b, B, model=model).step(pos, neg, 0.1)[:, 0]
+    torch.cuda.synchronize()
+    assert (loss_s - loss_p).abs().max().item() < SCORE_TOL
+    assert (a - b).abs().max().item() < 2e-5 * (d if model == "hole_spectral" else 1)   # spectral entries are d x larger
+
+
+def test_rank_sweep_model_argument(H):
+    """ge_rank_1vK: a real-valued HolE table is GE_ENOTSUP (transform it first), an unknown model GE_EINVAL."""
+    from graphembeddings_amd import _lib
+    emb = torch.zeros(64, 40, device="cuda")
+    hr = torch.zeros(4, 2, dtype=torch.int32, device="cuda")
+    tid = torch.ones(4, dtype=torch.int32, device="cuda")
+    cand = torch.arange(8, dtype=torch.int32, device="cuda")
+    nb = torch.zeros(4, dtype=torch.int32, device="cuda")
+    nk = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for model, code in ((1, _lib.GE_ENOTSUP), (3, _lib.GE_ENOTSUP), (7, _lib.GE_EINVAL)):
+        with pytest.raises(_lib.GeError) as e:
+            _lib.call("ge_rank_1vK", emb.data_ptr(), 64, 40, hr.data_ptr(), 4, tid.data_ptr(), cand.data_ptr(), 8, 1.0,
+                      model, 0, None, None, nb.data_ptr(), nk.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+        assert e.value.code == code
+    with pytest.raises(ValueError):
+        H.rank_candidates(emb, hr, tid, cand, model="hole")
+
+
 def _plans_equal(p, q):
     assert (p.S, p.B, p.sc, p.rc, p.req_start, p.unique_rows, p.remote_rows) == (q.S, q.B, q.sc, q.rc, q.req_start, q.unique_rows, q.remote_rows)
     assert torch.equal(p.remap, q.remap) and torch.equal(p.req_all, q.req_all)
