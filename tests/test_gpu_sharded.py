@@ -25,7 +25,7 @@ def _free_port():
 def _problem(name, world):
     from graphembeddings_amd import data as D
     from oracle import hole_oracle as O
-    if name == "fb15k":
+    if name in ("fb15k", "one_owner"):
         fb = D.fb15k_shape()
         names, id_to_type, offsets, ids = fb.type_arrays()
         table = O.init_table(fb.entity_count, 200, seed=4)
@@ -33,6 +33,15 @@ def _problem(name, world):
         B, steps = 512, 3                         # per rank
         tri = D.synthetic_fb15k_triples(fb, n_triples=world * steps * B, seed=6)
         padded = 1024
+        if name == "one_owner":
+            # every id odd (positives forced, candidate lists filtered): at world 2 rank 1 owns every row that is
+            # touched, so rank 1 requests NOTHING from rank 0 -- zero-length splits in all three all-to-alls
+            tri = tri | 1
+            keep = (ids & 1) == 1
+            c = np.concatenate([[0], np.cumsum(keep)])
+            cnt = c[offsets[1:]] - c[offsets[:-1]]
+            ids = ids[keep]
+            offsets = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
     else:                                         # BASELINE config 4
         B, steps = 16384, 2
         data, tri = D.synthetic_large(n_entities=1_200_000, n_triples=world * steps * B, seed=1234)
@@ -79,7 +88,7 @@ def _worker(rank, world, port, q, name):
         raise
 
 
-@pytest.mark.parametrize("name,world", [("fb15k", 2), ("fb15k", 4), ("config4", 2)])
+@pytest.mark.parametrize("name,world", [("fb15k", 2), ("fb15k", 4), ("config4", 2), ("one_owner", 2)])
 def test_sharded_real_kernels_match_c_port(name, world):
     import torch.multiprocessing as mp
     from oracle import c_oracle as CO
