@@ -128,6 +128,12 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     }
     const bool bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    // the six "applied by the producer" tags of this pair, requested together with its ids (not after the forward)
+    int32_t tag[6] = {0, 0, 0, 0, 0, 0};
+    if (slot_item && live) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
+    }
     Row<VEC, NITER> xp[3], xn[3];
 #pragma unroll
     for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, xp[X]);
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     for (int X = 0; X < 3; ++X) {
       const bool same = p[X] == n[X];
       const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
-      const bool dirP = slot_item && live && slot_item[rowP] == kSlotDirect;
-      const bool dirN = slot_item && live && !same && slot_item[rowN] == kSlotDirect;
+      const bool dirP = slot_item && live && tag[X] == kSlotDirect;
+      const bool dirN = slot_item && live && !same && tag[3 + X] == kSlotDirect;
       if (live && sub == 0) {
         grad_idx[rowP] = (on && !dirP) ? p[X] : -1;
         grad_idx[rowN] = (on && !same && !dirN) ? n[X] : -1;
