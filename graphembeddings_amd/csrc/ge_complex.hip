@@ -129,13 +129,10 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     const bool bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
     // the six "applied by the producer" tags of this pair, requested together with its ids (not after the forward)
-    // (unconditionally: a request inside a branch would make the row requests below wait for it; without a tag
-    // array the six words come from the table's first row and are never looked at)
-    int32_t tag[6];
-    {
-      const int32_t* tp = slot_item ? slot_item + (live ? g : 0) * 6 : reinterpret_cast<const int32_t*>(rows);
+    int32_t tag[6] = {0, 0, 0, 0, 0, 0};
+    if (slot_item && live) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) tag[c] = tp[c];
+      for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
     }
     Row<VEC, NITER> xp[3], xn[3];
 #pragma unroll

@@ -26,20 +26,15 @@ template <int VEC, int LPT, int NITER>
 __device__ __forceinline__ void load_row(const float* __restrict__ rows, int32_t id, int d, int k,
                                          int nvec, int sub, Row<VEC, NITER>& R) {
   const float* p = rows + (int64_t)id * d;
-  // Never a predicated request: lanes past the row's end request its last vector again and zero the result.
-  // (A load inside `if (j < nvec)` makes the compiler's waitcnt pass wait for ALL earlier requests before the
-  // next row's -- the six rows of a pair then arrive in two dependent round trips instead of one.)
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
     const int j = sub + it * LPT;
-    const int jc = j < nvec ? j : nvec - 1;
-    load_vec<VEC>(p + jc * VEC, R.re[it]);
-    load_vec<VEC>(p + k + jc * VEC, R.im[it]);
-    const bool in_row = j < nvec;
+    if (j < nvec) {
+      load_vec<VEC>(p + j * VEC, R.re[it]);
+      load_vec<VEC>(p + k + j * VEC, R.im[it]);
+    } else {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {               // selects, not a branch
-      R.re[it][v] = in_row ? R.re[it][v] : 0.f;
-      R.im[it][v] = in_row ? R.im[it][v] : 0.f;
+      for (int v = 0; v < VEC; ++v) { R.re[it][v] = 0.f; R.im[it][v] = 0.f; }
     }
   }
 }
