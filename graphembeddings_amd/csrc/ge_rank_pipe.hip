@@ -58,6 +58,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct Ops { float a0[4], a1[4], b0[4], b1[4]; };   // 4 k-pairs of this wave's 64 x 64 block: 2 A and 2 B fragments
 
 struct PipeLds {
+  _Float16* Ah;    // split-precision sweep only: [kRB][kSA] high halves of Q * 2^8 ...
+  _Float16* Am;    //   ... and the remainders (Q * 2^8 = Ah + Am to 22 bits)
+  _Float16* Bp;    //   [2 buffers][2 planes][kRB][kSB] candidate chunk * 2^4, high halves | remainders
   float* A;        // [kRB][lda]  q = fixed o relation, not yet scaled by the rows' clip scales
   float* Bs;       // [2][kRB][CW+1]
   float* sA;       // [kRB] product of the fixed and relation rows' clip scales (NaN: bad id / beyond B)
@@ -221,6 +224,142 @@ __device__ __forceinline__ void set_lane(int& m, unsigned v) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(v), "n"(LANE));
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision sweep (embedding_dim 200).  The fp32 MFMA tops out at 157 TFLOP/s; v_mfma_f32_32x32x16_f16 is 16x
+// faster.  x * 2^s = hi + mid with two fp16 values (round toward zero, so mid has hi's sign) is exact to 22 bits, and
+//     q . t  =  2^-12 (qh.th + qh.tm + qm.th)  +  O(2^-22) per product
+// accumulated in fp32: three f16 MFMAs per 16-wide k block instead of eight fp32 MFMAs.  Q (pre-multiplied by the
+// rows' clip scales, so |q| <= 1, scaled 2^8) sits in LDS as two fp16 planes -- the same 103 KB as fp32; a candidate
+// row (held whole in registers a tile ahead, so its clip scale is known first: |t clip(t)| <= 1, scaled 2^8) is
+// split chunk by chunk as it is stored to LDS.  No fp16 overflow for any table.  13 k blocks of 16 for d = 200 (208
+// columns, zero padded): chunks of two k blocks, the last of one.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int kFD = 200, kFKB = 13, kFChunks = 7;
+constexpr int kSA = 16 * kFKB + 8;      // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
+constexpr int kSB = 32 + 8;             // halves per candidate chunk row
+constexpr float kQScale = 256.f;   // both operands: |q|, |t * clip| <= 1
+
+struct F16Ops { h8 ah[2], am[2], bh[2], bm[2]; };
+
+constexpr size_t f16_lds_bytes() {
+  return sizeof(_Float16) * ((size_t)2 * kRB * kSA + 2 * 2 * kRB * kSB) + sizeof(float) * 3 * kRB + sizeof(float2) * kRB +
+         sizeof(unsigned) * kRB * 4 + sizeof(int) * 2 * kRB;
+}
+
+// slot c (chunk c of the row: 32 reals, this thread's 16) -- clamped to the row, zeroed when stored
+__device__ __forceinline__ void f16_fetch(const float* __restrict__ crow, int half, int c, float4 (&r)[4]) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const float4*>(crow + min(c * 32 + half * 16 + 4 * v, kFD - 4));
+}
+
+__device__ __forceinline__ void f16_split(float x0, float x1, float scale, h2& hi, h2& mid) {
+  x0 *= scale; x1 *= scale;
+  typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+  const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  hi = __builtin_bit_cast(h2, h);
+  const fp16x2 m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hi.x, x1 - (float)hi.y);
+  mid = __builtin_bit_cast(h2, m);
+}
+
+// half `part` (8 reals: two float4) of slot `C`, times `scale`, to the two planes of LDS buffer `buf`
+template <int C>
+__device__ __forceinline__ void f16_stash(const PipeLds& lds, int srow, int half, int buf, int part, const float4 (&r)[4],
+                                          float scale) {
+  float x[8] = {r[2 * part].x, r[2 * part].y, r[2 * part].z, r[2 * part].w,
+                r[2 * part + 1].x, r[2 * part + 1].y, r[2 * part + 1].z, r[2 * part + 1].w};
+  if (C == kFChunks - 1) {                      // the last slot holds columns 192..207: 200.. are padding
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (C * 32 + half * 16 + 8 * part + i < kFD) ? x[i] : 0.f;
+  }
+  h8 hi, mid;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h2 a, b;
+    f16_split(x[2 * i], x[2 * i + 1], scale, a, b);
+    hi[2 * i] = a.x; hi[2 * i + 1] = a.y; mid[2 * i] = b.x; mid[2 * i + 1] = b.y;
+  }
+  _Float16* dh = lds.Bp + ((buf * 2 + 0) * kRB + srow) * kSB + half * 16 + 8 * part;
+  _Float16* dm = lds.Bp + ((buf * 2 + 1) * kRB + srow) * kSB + half * 16 + 8 * part;
+  *reinterpret_cast<h8*>(dh) = hi;
+  *reinterpret_cast<h8*>(dm) = mid;
+}
+
+// piece i (0..7) of the operands of k block `kb`
+__device__ __forceinline__ void f16_ops_piece(F16Ops& o, const PipeLds& lds, int wm, int wn, int li, int lh, int kb, int i) {
+  const int t2 = i & 1;
+  const int buf = (kb >> 1) & 1, within = kb & 1;
+  const _Float16* ap = (i & 2 ? lds.Am : lds.Ah) + (wm * 64 + t2 * 32 + li) * kSA + kb * 16 + lh * 8;
+  const _Float16* bp = lds.Bp + ((buf * 2 + ((i >> 1) & 1)) * kRB + wn * 64 + t2 * 32 + li) * kSB + within * 16 + lh * 8;
+  if (i < 4) { if (i & 2) o.am[t2] = *reinterpret_cast<const h8*>(ap); else o.ah[t2] = *reinterpret_cast<const h8*>(ap); }
+  else { if (i & 2) o.bm[t2] = *reinterpret_cast<const h8*>(bp); else o.bh[t2] = *reinterpret_cast<const h8*>(bp); }
+}
+
+// One 128 x 128 tile on the f16 planes.  R[c] holds slot c of this tile's candidate row on entry and slot c of the
+// NEXT tile's row (next_row) on exit: a slot is refilled right after it has been stored to LDS, a whole tile ahead
+// of its use.
+__device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, bool bad, float max_norm, const PipeLds& lds,
+                                         float4 (&R)[kFChunks][4], f32x16 (&acc)[2][2]) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
+  const int srow = t >> 1, half = t & 1;
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  // The whole row is in registers, so its clip scale is known BEFORE anything is stored: the planes hold
+  // t * clip(t) * 2^8 (|.| <= 256: no fp16 overflow whatever the table holds) and the epilogue needs no column scale.
+  f2 ss2 = {0.f, 0.f};
+  static_for<0, kFChunks>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool in = c * 32 + half * 16 + 4 * v + 3 < kFD;       // compile-time true except in the last slot
+      const f2 xy = in ? f2{R[c][v].x, R[c][v].y} : f2{0.f, 0.f}, zw = in ? f2{R[c][v].z, R[c][v].w} : f2{0.f, 0.f};
+      ss2 = __builtin_elementwise_fma(xy, xy, ss2);
+      ss2 = __builtin_elementwise_fma(zw, zw, ss2);
+    }
+  });
+  float ss = ss2.x + ss2.y;
+  ss += __shfl_xor(ss, 1, kWave);
+  float inv;
+  const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
+  if (half == 0) lds.sB[srow] = bad ? __builtin_nanf("") : 1.0f;   // (the shared epilogue multiplies by it)
+  f16_stash<0>(lds, srow, half, 0, 0, R[0], scale);
+  f16_stash<0>(lds, srow, half, 0, 1, R[0], scale);
+  __syncthreads();
+  F16Ops ops[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f16_ops_piece(ops[0], lds, wm, wn, li, lh, 0, i);
+  static_for<0, kFKB>([&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value, qc = kb >> 1, within = kb & 1;
+    constexpr bool last_of_chunk = within == 1 || kb == kFKB - 1;
+    if (last_of_chunk && qc + 1 < kFChunks) __syncthreads();      // chunk qc+1 is in LDS; chunk qc-1's buffer is free
+    F16Ops& cur = ops[kb & 1];
+    F16Ops& nxt = ops[(kb + 1) & 1];
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+      const int ty = p >> 2, tm = (p >> 1) & 1, tn = p & 1;       // consecutive MFMAs hit different accumulators
+      const h8 a = ty == 0 ? cur.am[tm] : cur.ah[tm];
+      const h8 b = ty == 1 ? cur.bm[tn] : cur.bh[tn];
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p < 8) {
+        if (kb + 1 < kFKB) f16_ops_piece(nxt, lds, wm, wn, li, lh, kb + 1, p);
+      } else if (!last_of_chunk) {                                // first k block of a chunk: store chunk qc+1
+        if (p < 10 && qc + 1 < kFChunks) f16_stash<qc + 1>(lds, srow, half, (qc + 1) & 1, p - 8, R[qc + 1], scale);
+      } else {                                                    // last k block: refill the slot just stored
+        constexpr int slot = qc + 1 < kFChunks ? qc + 1 : 0;
+        R[slot][p - 8] = *reinterpret_cast<const float4*>(next_row + min(slot * 32 + half * 16 + 4 * (p - 8), kFD - 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  });
+  __syncthreads();                              // the bitmask / bracket arrays of the epilogue are free again
+}
+
 // m = 2 * m + (this lane's bit of the wave mask): one v_addc_co_u32 with the mask as carry-in
 __device__ __forceinline__ void shift_in(unsigned& m, unsigned long long mask) {
   unsigned long long carry_out;
@@ -246,7 +385,7 @@ __device__ __forceinline__ void exact_masks(const PipeLds& lds, float x0, float 
 
 // MODE 0: ranks.  1: ranks, every loss computed exactly and stored too (tests).  2: no ranking at all -- the sweep
 // writes scores_out[B,K] (raw score, or its sigmoid when `sweep_flags` & 1): ge_complex_score_1vK on this pipeline.
-template <int CW, int NCH, int MODE>
+template <int CW, int NCH, int MODE, bool F16 = false>
 __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
@@ -259,9 +398,18 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lda = d + 1;
   PipeLds lds;
-  lds.A = smem;
-  lds.Bs = lds.A + kRB * lda;
-  lds.sA = lds.Bs + 2 * kRB * C::kLdb;
+  if constexpr (F16) {
+    lds.Ah = reinterpret_cast<_Float16*>(smem);
+    lds.Am = lds.Ah + kRB * kSA;
+    lds.Bp = lds.Am + kRB * kSA;
+    lds.A = lds.Bs = nullptr;
+    lds.sA = reinterpret_cast<float*>(lds.Bp + 2 * 2 * kRB * kSB);
+  } else {
+    lds.Ah = lds.Am = lds.Bp = nullptr;
+    lds.A = smem;
+    lds.Bs = lds.A + kRB * lda;
+    lds.sA = lds.Bs + 2 * kRB * C::kLdb;
+  }
   lds.sB = lds.sA + kRB;
   lds.eT = lds.sB + kRB;
   lds.lohi = reinterpret_cast<float2*>(lds.eT + kRB);             // an even number of floats in: 8-byte aligned
@@ -284,8 +432,60 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     idx += ct1 - ct0;
     __syncthreads();                                             // the previous row block's LDS is done with
 
-    // ---- Q = fixed o relation for the block's 128 rows, whole k range; the clip scales stay a per-row factor
-    {
+    // ---- Q = fixed o relation for the block's 128 rows
+    if constexpr (F16) {     // scaled by the rows' clip scales and 2^8, split into two fp16 planes (see f16_tile)
+      const int64_t r = m0 + srow;
+      int32_t fid = -1, rid = -1;
+      if (r < B) { fid = hr[2 * r]; rid = hr[2 * r + 1]; }
+      const bool bad = fid < 0 || fid >= N || rid < 0 || rid >= N;
+      const float* frow = table + (int64_t)(bad ? 0 : fid) * d;
+      const float* rrow = table + (int64_t)(bad ? 0 : rid) * d;
+      float ssf = 0.f, ssr = 0.f;
+      for (int j = half; j < (k >> 2); j += 2) {                 // pass 1: the two clip norms
+        const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
+        const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
+        ssf += fre.x * fre.x + fre.y * fre.y + fre.z * fre.z + fre.w * fre.w + fim.x * fim.x + fim.y * fim.y + fim.z * fim.z + fim.w * fim.w;
+        ssr += rre.x * rre.x + rre.y * rre.y + rre.z * rre.z + rre.w * rre.w + rim.x * rim.x + rim.y * rim.y + rim.z * rim.z + rim.w * rim.w;
+      }
+      ssf += __shfl_xor(ssf, 1, kWave);
+      ssr += __shfl_xor(ssr, 1, kWave);
+      float i0, i1;
+      const float sa = clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+      _Float16* ah = lds.Ah + srow * kSA;
+      _Float16* am = lds.Am + srow * kSA;
+      for (int j = half; j < (k >> 2); j += 2) {                 // pass 2: q * sa * 2^8 -> high halves and remainders
+        const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
+        const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
+        const float fr[4] = {fre.x, fre.y, fre.z, fre.w}, fi[4] = {fim.x, fim.y, fim.z, fim.w};
+        const float rr[4] = {rre.x, rre.y, rre.z, rre.w}, ri[4] = {rim.x, rim.y, rim.z, rim.w};
+        float qre[4], qim[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
+            qre[i] = fr[i] * rr[i] - fi[i] * ri[i];
+            qim[i] = fr[i] * ri[i] + fi[i] * rr[i];
+          } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
+            qre[i] = rr[i] * fr[i] + ri[i] * fi[i];
+            qim[i] = -(ri[i] * fr[i] - rr[i] * fi[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          h2 a, b;
+          f16_split(qre[i] * sa, qre[i + 1] * sa, kQScale, a, b);
+          ah[4 * j + i] = a.x; ah[4 * j + i + 1] = a.y; am[4 * j + i] = b.x; am[4 * j + i + 1] = b.y;
+          f16_split(qim[i] * sa, qim[i + 1] * sa, kQScale, a, b);
+          ah[k + 4 * j + i] = a.x; ah[k + 4 * j + i + 1] = a.y; am[k + 4 * j + i] = b.x; am[k + 4 * j + i + 1] = b.y;
+        }
+      }
+      if (half == 0) {
+        for (int c = kFD; c < 16 * kFKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }   // k padding
+        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
+        lds.skip[srow] = 0;
+        lds.tI[srow] = (MODE != 2 && r < B) ? true_id[r] : -1;
+      }
+    } else
+    {   // whole k range in fp32; the clip scales stay a per-row factor
       const int64_t r = m0 + srow;
       int32_t fid = -1, rid = -1;
       if (r < B) { fid = hr[2 * r]; rid = hr[2 * r + 1]; }
@@ -335,14 +535,36 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     }
     __syncthreads();
 
+    auto cand_of = [&](int ct) -> int32_t {
+      const int64_t c = (int64_t)ct * kRB + srow;
+      return (ct < ct1 && c < K) ? cand[c] : -1;
+    };
+    auto known_of = [&](int ct, int32_t& k0, int32_t& k1) {
+      k0 = k1 = 0;
+      if (known_off && ct < ct1) {
+        const int64_t tile = (int64_t)rb * n_ct + ct;
+        k0 = known_off[tile]; k1 = known_off[tile + 1];
+      }
+    };
     f32x16 acc[2][2];
     float4 rA[NV], rB[NV];
+    float4 R[F16 ? kFChunks : 1][4];                              // split-precision sweep: the whole candidate row, by slot
+    auto row_of = [&](int32_t id) -> const float* {               // (bad ids read row 0; their clip scale is NaN)
+      return table + (int64_t)((id < 0 || id >= N) ? 0 : id) * d;
+    };
     // ---- the true candidates: a tile whose candidate rows are this block's 128 true entities
     if constexpr (MODE != 2) {
       const int32_t tid = lds.tI[srow];
-      pipe_fetch<CW>(table, N, d, tid, 0, rA);
-      pipe_fetch<CW>(table, N, d, tid, 1, rB);
-      pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, spec, lds, rA, rB, acc);
+      if constexpr (F16) {
+        const float* trow = row_of(tid);
+#pragma unroll
+        for (int c = 0; c < kFChunks; ++c) f16_fetch(trow, half, c, R[c]);
+        f16_tile(row_of(cand_of(ct0)), tid < 0 || tid >= N, max_norm, lds, R, acc);   // leaves the first tile's row in R
+      } else {
+        pipe_fetch<CW>(table, N, d, tid, 0, rA);
+        pipe_fetch<CW>(table, N, d, tid, 1, rB);
+        pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, spec, lds, rA, rB, acc);
+      }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -373,28 +595,28 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     int raw_reg = 0;
 
     // ---- the sweep over this share's candidate tiles of the row block
-    auto cand_of = [&](int ct) -> int32_t {
-      const int64_t c = (int64_t)ct * kRB + srow;
-      return (ct < ct1 && c < K) ? cand[c] : -1;
-    };
-    auto known_of = [&](int ct, int32_t& k0, int32_t& k1) {
-      k0 = k1 = 0;
-      if (known_off && ct < ct1) {
-        const int64_t tile = (int64_t)rb * n_ct + ct;
-        k0 = known_off[tile]; k1 = known_off[tile + 1];
-      }
-    };
     // candidate ids and known-cell ranges are requested one tile ahead of their use: nothing ever waits on them
     int32_t cid = cand_of(ct0), cid_next = cand_of(ct0 + 1), kn0, kn1, kn0_next, kn1_next;
     known_of(ct0, kn0_next, kn1_next);
-    pipe_fetch<CW>(table, N, d, cid, 0, rA);
-    pipe_fetch<CW>(table, N, d, cid, 1, rB);
+    if constexpr (F16) {
+      if constexpr (MODE == 2) {                                  // no diagonal tile ran: the first row is not in R yet
+        const float* crow0 = row_of(cid);
+#pragma unroll
+        for (int c = 0; c < kFChunks; ++c) f16_fetch(crow0, half, c, R[c]);
+      }
+    } else {
+      pipe_fetch<CW>(table, N, d, cid, 0, rA);
+      pipe_fetch<CW>(table, N, d, cid, 1, rB);
+    }
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
-      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
+      if constexpr (F16) f16_tile(row_of(cid_next), cid < 0 || cid >= N, max_norm, lds, R, acc);
+      else pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
       cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
-      pipe_fetch<CW>(table, N, d, cid, 0, rA);                   // land while the epilogue below runs
-      pipe_fetch<CW>(table, N, d, cid, 1, rB);
+      if constexpr (!F16) {
+        pipe_fetch<CW>(table, N, d, cid, 0, rA);                 // land while the epilogue below runs
+        pipe_fetch<CW>(table, N, d, cid, 1, rB);
+      }
       cid_next = cand_of(ct + 2);
       known_of(ct + 1, kn0_next, kn1_next);
       // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -529,6 +751,20 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                        cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec, sweep_flags);
     return launch_status();
   };
+  if constexpr (CW == 40) if (d == kFD && !spec) {                // split-precision sweep (fp16 hi/mid planes)
+    auto go16 = [&](auto kern) -> int {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), f16_lds_bytes(), st, table, N, d, hr, B, true_id, cand, K,
+                         max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct,
+                         n_tiles, spec, sweep_flags);
+      return launch_status();
+    };
+    if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, true>);
+    if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, true>);
+    return go16(rank_pipe_kernel<CW, 0, 0, true>);
+  }
   if (scores_only) return (CW == 40 && d == 200) ? go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 2>) : go(rank_pipe_kernel<CW, 0, 2>);
   if (scores_out) return go(rank_pipe_kernel<CW, 0, 1>);
   if (CW == 40 && d == 200) return go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 0>);   // the FB15k configuration, unrolled
