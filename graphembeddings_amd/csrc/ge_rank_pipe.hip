@@ -235,22 +235,29 @@ __device__ __forceinline__ void set_lane(int& m, unsigned v) {
 // columns, zero padded): chunks of two k blocks, the last of one.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-constexpr int kFD = 200, kFKB = 13, kFChunks = 7;
-constexpr int kSA = 16 * kFKB + 8;      // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
+template <int D>
+struct FCfg {                           // D = embedding_dim, compiled for 64, 128 and 200
+  static constexpr int kKB = (D + 15) / 16;       // k blocks of 16 (the last zero padded)
+  static constexpr int kChunks = (kKB + 1) / 2;   // staged chunks of two k blocks = register slots of 32 reals
+  static constexpr int kSA = 16 * kKB + 8;        // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
+  static_assert(D % 8 == 0 && D >= 64 && D <= 224, "embedding_dim of the split-precision sweep");
+};
 constexpr int kSB = 32 + 8;             // halves per candidate chunk row
 constexpr float kQScale = 256.f;   // both operands: |q|, |t * clip| <= 1
 
 struct F16Ops { h8 ah[2], am[2], bh[2], bm[2]; };
 
+template <int D>
 constexpr size_t f16_lds_bytes() {
-  return sizeof(_Float16) * ((size_t)2 * kRB * kSA + 2 * 2 * kRB * kSB) + sizeof(float) * 3 * kRB + sizeof(float2) * kRB +
+  return sizeof(_Float16) * ((size_t)2 * kRB * FCfg<D>::kSA + 2 * 2 * kRB * kSB) + sizeof(float) * 3 * kRB + sizeof(float2) * kRB +
          sizeof(unsigned) * kRB * 4 + sizeof(int) * 2 * kRB;
 }
 
 // slot c (chunk c of the row: 32 reals, this thread's 16) -- clamped to the row, zeroed when stored
+template <int D>
 __device__ __forceinline__ void f16_fetch(const float* __restrict__ crow, int half, int c, float4 (&r)[4]) {
 #pragma unroll
-  for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const float4*>(crow + min(c * 32 + half * 16 + 4 * v, kFD - 4));
+  for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const float4*>(crow + min(c * 32 + half * 16 + 4 * v, D - 4));
 }
 
 __device__ __forceinline__ void f16_split(float x0, float x1, float scale, h2& hi, h2& mid) {
@@ -263,14 +270,14 @@ __device__ __forceinline__ void f16_split(float x0, float x1, float scale, h2& h
 }
 
 // half `part` (8 reals: two float4) of slot `C`, times `scale`, to the two planes of LDS buffer `buf`
-template <int C>
+template <int D, int C>
 __device__ __forceinline__ void f16_stash(const PipeLds& lds, int srow, int half, int buf, int part, const float4 (&r)[4],
                                           float scale) {
   float x[8] = {r[2 * part].x, r[2 * part].y, r[2 * part].z, r[2 * part].w,
                 r[2 * part + 1].x, r[2 * part + 1].y, r[2 * part + 1].z, r[2 * part + 1].w};
-  if (C == kFChunks - 1) {                      // the last slot holds columns 192..207: 200.. are padding
+  if (C == FCfg<D>::kChunks - 1) {              // the last slot may reach past the row (d = 200: columns 200..223)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = (C * 32 + half * 16 + 8 * part + i < kFD) ? x[i] : 0.f;
+    for (int i = 0; i < 8; ++i) x[i] = (C * 32 + half * 16 + 8 * part + i < D) ? x[i] : 0.f;
   }
   h8 hi, mid;
 #pragma unroll
@@ -286,7 +293,9 @@ __device__ __forceinline__ void f16_stash(const PipeLds& lds, int srow, int half
 }
 
 // piece i (0..7) of the operands of k block `kb`
+template <int D>
 __device__ __forceinline__ void f16_ops_piece(F16Ops& o, const PipeLds& lds, int wm, int wn, int li, int lh, int kb, int i) {
+  constexpr int kSA = FCfg<D>::kSA;
   const int t2 = i & 1;
   const int buf = (kb >> 1) & 1, within = kb & 1;
   const _Float16* ap = (i & 2 ? lds.Am : lds.Ah) + (wm * 64 + t2 * 32 + li) * kSA + kb * 16 + lh * 8;
@@ -298,8 +307,10 @@ __device__ __forceinline__ void f16_ops_piece(F16Ops& o, const PipeLds& lds, int
 // One 128 x 128 tile on the f16 planes.  R[c] holds slot c of this tile's candidate row on entry and slot c of the
 // NEXT tile's row (next_row) on exit: a slot is refilled right after it has been stored to LDS, a whole tile ahead
 // of its use.
+template <int D>
 __device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, bool bad, float max_norm, const PipeLds& lds,
-                                         float4 (&R)[kFChunks][4], f32x16 (&acc)[2][2]) {
+                                         float4 (&R)[FCfg<D>::kChunks][4], f32x16 (&acc)[2][2]) {
+  constexpr int kFD = D, kFKB = FCfg<D>::kKB, kFChunks = FCfg<D>::kChunks;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int srow = t >> 1, half = t & 1;
   const int li = lane & 31, lh = lane >> 5;
@@ -327,12 +338,12 @@ __device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, boo
   float inv;
   const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
   if (half == 0) lds.sB[srow] = bad ? __builtin_nanf("") : 1.0f;   // (the shared epilogue multiplies by it)
-  f16_stash<0>(lds, srow, half, 0, 0, R[0], scale);
-  f16_stash<0>(lds, srow, half, 0, 1, R[0], scale);
+  f16_stash<D, 0>(lds, srow, half, 0, 0, R[0], scale);
+  f16_stash<D, 0>(lds, srow, half, 0, 1, R[0], scale);
   __syncthreads();
   F16Ops ops[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) f16_ops_piece(ops[0], lds, wm, wn, li, lh, 0, i);
+  for (int i = 0; i < 8; ++i) f16_ops_piece<D>(ops[0], lds, wm, wn, li, lh, 0, i);
   static_for<0, kFKB>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value, qc = kb >> 1, within = kb & 1;
     constexpr bool last_of_chunk = within == 1 || kb == kFKB - 1;
@@ -347,9 +358,9 @@ __device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, boo
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm][tn], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (p < 8) {
-        if (kb + 1 < kFKB) f16_ops_piece(nxt, lds, wm, wn, li, lh, kb + 1, p);
+        if (kb + 1 < kFKB) f16_ops_piece<D>(nxt, lds, wm, wn, li, lh, kb + 1, p);
       } else if (!last_of_chunk) {                                // first k block of a chunk: store chunk qc+1
-        if (p < 10 && qc + 1 < kFChunks) f16_stash<qc + 1>(lds, srow, half, (qc + 1) & 1, p - 8, R[qc + 1], scale);
+        if (p < 10 && qc + 1 < kFChunks) f16_stash<D, (qc + 1 < kFChunks ? qc + 1 : 0)>(lds, srow, half, (qc + 1) & 1, p - 8, R[qc + 1 < kFChunks ? qc + 1 : 0], scale);
       } else {                                                    // last k block: refill the slot just stored
         constexpr int slot = qc + 1 < kFChunks ? qc + 1 : 0;
         R[slot][p - 8] = *reinterpret_cast<const float4*>(next_row + min(slot * 32 + half * 16 + 4 * (p - 8), kFD - 4));
@@ -385,7 +396,7 @@ __device__ __forceinline__ void exact_masks(const PipeLds& lds, float x0, float 
 
 // MODE 0: ranks.  1: ranks, every loss computed exactly and stored too (tests).  2: no ranking at all -- the sweep
 // writes scores_out[B,K] (raw score, or its sigmoid when `sweep_flags` & 1): ge_complex_score_1vK on this pipeline.
-template <int CW, int NCH, int MODE, bool F16 = false>
+template <int CW, int NCH, int MODE, int FD = 0>   // FD > 0: the split-precision sweep compiled for embedding_dim FD
 __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
@@ -393,6 +404,9 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
     float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags) {
   constexpr bool SCORES = MODE == 1;
+  constexpr bool F16 = FD > 0;
+  constexpr int DF = F16 ? FD : 64;                               // (any valid value where the f16 code is discarded)
+  constexpr int kFD = DF, kFKB = FCfg<DF>::kKB, kFChunks = FCfg<DF>::kChunks, kSA = FCfg<DF>::kSA;
   using C = Cfg<CW>;
   constexpr int NV = C::kNV;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -558,8 +572,8 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       if constexpr (F16) {
         const float* trow = row_of(tid);
 #pragma unroll
-        for (int c = 0; c < kFChunks; ++c) f16_fetch(trow, half, c, R[c]);
-        f16_tile(row_of(cand_of(ct0)), tid < 0 || tid >= N, max_norm, lds, R, acc);   // leaves the first tile's row in R
+        for (int c = 0; c < kFChunks; ++c) f16_fetch<DF>(trow, half, c, R[c]);
+        f16_tile<DF>(row_of(cand_of(ct0)), tid < 0 || tid >= N, max_norm, lds, R, acc);   // leaves the first tile's row in R
       } else {
         pipe_fetch<CW>(table, N, d, tid, 0, rA);
         pipe_fetch<CW>(table, N, d, tid, 1, rB);
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       if constexpr (MODE == 2) {                                  // no diagonal tile ran: the first row is not in R yet
         const float* crow0 = row_of(cid);
 #pragma unroll
-        for (int c = 0; c < kFChunks; ++c) f16_fetch(crow0, half, c, R[c]);
+        for (int c = 0; c < kFChunks; ++c) f16_fetch<DF>(crow0, half, c, R[c]);
       }
     } else {
       pipe_fetch<CW>(table, N, d, cid, 0, rA);
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     }
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
-      if constexpr (F16) f16_tile(row_of(cid_next), cid < 0 || cid >= N, max_norm, lds, R, acc);
+      if constexpr (F16) f16_tile<DF>(row_of(cid_next), cid < 0 || cid >= N, max_norm, lds, R, acc);
       else pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
       cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
       if constexpr (!F16) {
@@ -668,7 +682,8 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
           static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
             const float2 br = lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh];
-            const float x0 = acc[tm][0][q] * sb0, x1 = acc[tm][1][q] * sb1;
+            // (split-precision sweep: the candidate planes already carry the clip scale)
+            const float x0 = F16 ? acc[tm][0][q] : acc[tm][0][q] * sb0, x1 = F16 ? acc[tm][1][q] : acc[tm][1][q] * sb1;
             const unsigned long long lt0 = __ballot(x0 < br.x), lt1 = __ballot(x1 < br.x);
             shift_in(L0, lt0);
             shift_in(L1, lt1);
@@ -751,20 +766,25 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                        cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec, sweep_flags);
     return launch_status();
   };
-  if constexpr (CW == 40) if (d == kFD && !spec) {                // split-precision sweep (fp16 hi/mid planes)
-    auto go16 = [&](auto kern) -> int {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), f16_lds_bytes(), st, table, N, d, hr, B, true_id, cand, K,
-                         max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct,
-                         n_tiles, spec, sweep_flags);
-      return launch_status();
-    };
-    if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, true>);
-    if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, true>);
-    return go16(rank_pipe_kernel<CW, 0, 0, true>);
+  // split-precision sweep (fp16 hi/mid planes, f16 MFMA): the dims it is compiled for, ComplEx tables
+  auto go16 = [&](auto kern, size_t lds16) -> int {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds16, st, table, N, d, hr, B, true_id, cand, K,
+                       max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct,
+                       n_tiles, spec, sweep_flags);
+    return launch_status();
+  };
+#define GE_F16(DD)                                                                                     \
+  if (d == DD && !spec) {                                                                              \
+    if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, DD>, f16_lds_bytes<DD>());                 \
+    if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, DD>, f16_lds_bytes<DD>());                  \
+    return go16(rank_pipe_kernel<CW, 0, 0, DD>, f16_lds_bytes<DD>());                                  \
   }
+  if constexpr (CW == 40) { GE_F16(200) }
+  if constexpr (CW == 32) { GE_F16(64) GE_F16(128) }
+#undef GE_F16
   if (scores_only) return (CW == 40 && d == 200) ? go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 2>) : go(rank_pipe_kernel<CW, 0, 2>);
   if (scores_out) return go(rank_pipe_kernel<CW, 0, 1>);
   if (CW == 40 && d == 200) return go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 0>);   // the FB15k configuration, unrolled

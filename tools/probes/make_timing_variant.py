@@ -17,22 +17,24 @@ def rep(old, new):
 rep("  while (idx < idx_end) {\n    const int rb",
     "  long long T0, T_setup = 0, T_diag = 0, T_tile = 0, T_epi = 0, T_epi2 = 0; int n_t = 0, n_seg = 0;\n"
     "  while (idx < idx_end) {\n    T0 = clock64(); ++n_seg;\n    const int rb")
-rep("    __syncthreads();\n\n    f32x16 acc[2][2];",
-    "    __syncthreads();\n    T_setup += clock64() - T0; T0 = clock64();\n\n    f32x16 acc[2][2];")
+rep("    __syncthreads();\n\n    auto cand_of = ",
+    "    __syncthreads();\n    T_setup += clock64() - T0; T0 = clock64();\n\n    auto cand_of = ")
 rep("    int raw_reg = 0;\n", "    int raw_reg = 0;\n    T_diag += clock64() - T0;\n")
-rep("      const int64_t n0 = (int64_t)ct * kRB;\n      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);\n",
+rep("      const int64_t n0 = (int64_t)ct * kRB;\n      if constexpr (F16) f16_tile(row_of(cid_next), cid < 0 || cid >= N, max_norm, lds, R, acc);\n"
+    "      else pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);\n",
     "      const int64_t n0 = (int64_t)ct * kRB;\n      T0 = clock64();\n"
-    "      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, lds, rA, rB, acc);\n"
+    "      if constexpr (F16) f16_tile(row_of(cid_next), cid < 0 || cid >= N, max_norm, lds, R, acc);\n"
+    "      else pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);\n"
     "      T_tile += clock64() - T0; T0 = clock64(); ++n_t;\n")
 rep("      __syncthreads();\n      if (t < kRB) {\n        const unsigned* m = lds.bm + t * 4;",
     "      T_epi += clock64() - T0; T0 = clock64();\n      __syncthreads();\n      if (t < kRB) {\n"
     "        const unsigned* m = lds.bm + t * 4;")
 rep("      // no barrier: the next tile's first write", "      T_epi2 += clock64() - T0;\n      // no barrier: the next tile's first write")
-rep("    if (t < kRB && m0 + t < B) {\n      if (raw_reg) atomicAdd",
+rep("    if (MODE != 2 && t < kRB && m0 + t < B) {\n      if (raw_reg) atomicAdd",
     "    if (true_loss && blockIdx.x == 7 && t == 0 && idx >= idx_end) {\n"
     "      true_loss[0] = (float)T_setup; true_loss[1] = (float)T_diag; true_loss[2] = (float)T_tile; true_loss[3] = (float)T_epi;\n"
     "      true_loss[4] = (float)n_t; true_loss[5] = (float)T_epi2; true_loss[6] = (float)n_seg;\n    }\n"
-    "    if (t < kRB && m0 + t < B) {\n      if (raw_reg) atomicAdd")
+    "    if (MODE != 2 && t < kRB && m0 + t < B) {\n      if (raw_reg) atomicAdd")
 # ablations (wrong results, timing only): -DGE_ABL=bits  2: no chunk barrier, 4: no LDS stores of
 # the staged chunk, 8: no global requests
 rep('#include "ge_rank_dev.h"\n', '#include "ge_rank_dev.h"\n#ifndef GE_ABL\n#define GE_ABL 0\n#endif\n')
