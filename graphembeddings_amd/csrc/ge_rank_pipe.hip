@@ -308,8 +308,8 @@ __device__ __forceinline__ void f16_ops_piece(F16Ops& o, const PipeLds& lds, int
 // NEXT tile's row (next_row) on exit: a slot is refilled right after it has been stored to LDS, a whole tile ahead
 // of its use.
 template <int D>
-__device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, bool bad, float max_norm, const PipeLds& lds,
-                                         float4 (&R)[FCfg<D>::kChunks][4], f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, bool bad, float max_norm, int spec,
+                                         const PipeLds& lds, float4 (&R)[FCfg<D>::kChunks][4], f32x16 (&acc)[2][2]) {
   constexpr int kFD = D, kFKB = FCfg<D>::kKB, kFChunks = FCfg<D>::kChunks;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int srow = t >> 1, half = t & 1;
@@ -334,7 +334,14 @@ __device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, boo
     }
   });
   float ss = ss2.x + ss2.y;
+  // spectral HolE rows: |x|^2 = (2 sum - X_0^2 - X_k^2) / d; the two real bins sit at columns 0 and d/2
+  constexpr int kNy = D / 2, kNySlot = kNy / 32, kNyHalf = (kNy % 32) / 16, kNyV = (kNy % 16) / 4, kNyC = kNy % 4;
+  const float4 nyv = R[kNySlot][kNyV];
+  const float x_ny = kNyC == 0 ? nyv.x : kNyC == 1 ? nyv.y : kNyC == 2 ? nyv.z : nyv.w, x_dc = R[0][0].x;
+  float corr = (half == 0 ? x_dc * x_dc : 0.f) + (half == kNyHalf ? x_ny * x_ny : 0.f);
   ss += __shfl_xor(ss, 1, kWave);
+  corr += __shfl_xor(corr, 1, kWave);
+  if (spec) ss = (2.f * ss - corr) / (float)D;
   float inv;
   const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
   if (half == 0) lds.sB[srow] = bad ? __builtin_nanf("") : 1.0f;   // (the shared epilogue multiplies by it)
@@ -455,16 +462,20 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       const float* frow = table + (int64_t)(bad ? 0 : fid) * d;
       const float* rrow = table + (int64_t)(bad ? 0 : rid) * d;
       float ssf = 0.f, ssr = 0.f;
+      // spectral HolE (ge_complex_dev.h): Hermitian weight 2 on every bin but element 0, which packs the two REAL
+      // bins X_0 | X_k; norms and score carry the Parseval factor 1/d
       for (int j = half; j < (k >> 2); j += 2) {                 // pass 1: the two clip norms
         const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
         const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
-        ssf += fre.x * fre.x + fre.y * fre.y + fre.z * fre.z + fre.w * fre.w + fim.x * fim.x + fim.y * fim.y + fim.z * fim.z + fim.w * fim.w;
-        ssr += rre.x * rre.x + rre.y * rre.y + rre.z * rre.z + rre.w * rre.w + rim.x * rim.x + rim.y * rim.y + rim.z * rim.z + rim.w * rim.w;
+        const float w0 = (spec && j != 0) ? 2.f : 1.f, w1 = spec ? 2.f : 1.f;     // element 0 of the row / the others
+        ssf += w0 * (fre.x * fre.x + fim.x * fim.x) + w1 * (fre.y * fre.y + fre.z * fre.z + fre.w * fre.w + fim.y * fim.y + fim.z * fim.z + fim.w * fim.w);
+        ssr += w0 * (rre.x * rre.x + rim.x * rim.x) + w1 * (rre.y * rre.y + rre.z * rre.z + rre.w * rre.w + rim.y * rim.y + rim.z * rim.z + rim.w * rim.w);
       }
       ssf += __shfl_xor(ssf, 1, kWave);
       ssr += __shfl_xor(ssr, 1, kWave);
       float i0, i1;
-      const float sa = clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+      const float inv_d = spec ? 1.0f / (float)d : 1.0f;
+      const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1);
       _Float16* ah = lds.Ah + srow * kSA;
       _Float16* am = lds.Am + srow * kSA;
       for (int j = half; j < (k >> 2); j += 2) {                 // pass 2: q * sa * 2^8 -> high halves and remainders
@@ -475,13 +486,18 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         float qre[4], qim[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
+          const bool packed = spec && j == 0 && i == 0;
+          if (packed) {          // two independent real dimensions: products of the re slots and of the im slots
+            qre[i] = fr[i] * rr[i];
+            qim[i] = fi[i] * ri[i];
+          } else if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
             qre[i] = fr[i] * rr[i] - fi[i] * ri[i];
             qim[i] = fr[i] * ri[i] + fi[i] * rr[i];
           } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
             qre[i] = rr[i] * fr[i] + ri[i] * fi[i];
             qim[i] = -(ri[i] * fr[i] - rr[i] * fi[i]);
           }
+          if (spec && !packed) { qre[i] *= 2.f; qim[i] *= 2.f; }   // |q sa| <= 2: still far inside fp16 after the 2^8
         }
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       }
       if (half == 0) {
         for (int c = kFD; c < 16 * kFKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }   // k padding
-        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
+        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : inv_d / (kQScale * kQScale);
         lds.skip[srow] = 0;
         lds.tI[srow] = (MODE != 2 && r < B) ? true_id[r] : -1;
       }
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         const float* trow = row_of(tid);
 #pragma unroll
         for (int c = 0; c < kFChunks; ++c) f16_fetch<DF>(trow, half, c, R[c]);
-        f16_tile<DF>(row_of(cand_of(ct0)), tid < 0 || tid >= N, max_norm, lds, R, acc);   // leaves the first tile's row in R
+        f16_tile<DF>(row_of(cand_of(ct0)), tid < 0 || tid >= N, max_norm, spec, lds, R, acc);   // leaves the first tile's row in R
       } else {
         pipe_fetch<CW>(table, N, d, tid, 0, rA);
         pipe_fetch<CW>(table, N, d, tid, 1, rB);
@@ -624,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     }
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
-      if constexpr (F16) f16_tile<DF>(row_of(cid_next), cid < 0 || cid >= N, max_norm, lds, R, acc);
+      if constexpr (F16) f16_tile<DF>(row_of(cid_next), cid < 0 || cid >= N, max_norm, spec, lds, R, acc);
       else pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
       cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
       if constexpr (!F16) {
@@ -766,7 +782,7 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                        cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec, sweep_flags);
     return launch_status();
   };
-  // split-precision sweep (fp16 hi/mid planes, f16 MFMA): the dims it is compiled for, ComplEx tables
+  // split-precision sweep (fp16 hi/mid planes, f16 MFMA): the dims it is compiled for, ComplEx and spectral HolE tables
   auto go16 = [&](auto kern, size_t lds16) -> int {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
@@ -777,7 +793,7 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
     return launch_status();
   };
 #define GE_F16(DD)                                                                                     \
-  if (d == DD && !spec) {                                                                              \
+  if (d == DD) {                                                                                       \
     if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, DD>, f16_lds_bytes<DD>());                 \
     if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, DD>, f16_lds_bytes<DD>());                  \
     return go16(rank_pipe_kernel<CW, 0, 0, DD>, f16_lds_bytes<DD>());                                  \

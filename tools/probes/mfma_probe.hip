@@ -93,6 +93,49 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, int ite
   if (blockIdx.x == 0 && t == 0) *cyc = c1 - c0;
 }
 
+// f16 MFMA (32 cycles each): NF independent FMAs after every MFMA -- do they hide in the gap?
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+template <int NF>
+__global__ __launch_bounds__(256) void probe_f16(float* out, long long* cyc, int iters) {
+  const int t = threadIdx.x, lane = t & 63;
+  f32x16 acc[2][2];
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+  h8 A[2], B[2];
+  for (int i = 0; i < 8; ++i) { A[0][i] = (_Float16)(0.5f + i); A[1][i] = (_Float16)(0.25f * lane); B[0][i] = (_Float16)(0.125f * i); B[1][i] = (_Float16)1.f; }
+  float v0 = lane, v1 = 2.f * lane, v2 = 0.5f, v3 = 1.5f;
+  long long c0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int p = 0; p < 24; ++p) {
+      acc[(p >> 1) & 1][p & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(p >> 1) & 1], B[p & 1], acc[(p >> 1) & 1][p & 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < NF; ++r) {
+        if ((r & 3) == 0) v0 = __builtin_fmaf(v0, 1.0001f, 0.5f);
+        else if ((r & 3) == 1) v1 = __builtin_fmaf(v1, 0.9999f, 0.25f);
+        else if ((r & 3) == 2) v2 = __builtin_fmaf(v2, 1.0002f, 0.125f);
+        else v3 = __builtin_fmaf(v3, 0.9998f, 0.0625f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  long long c1 = clock64();
+  float s = 0.f;
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int q = 0; q < 16; ++q) s += acc[a][b][q];
+  out[blockIdx.x * 256 + t] = s + v0 + v1 + v2 + v3;
+  if (blockIdx.x == 0 && t == 0) *cyc = c1 - c0;
+}
+
+template <int NF>
+void run_f16(float* out, long long* cyc, int iters) {
+  probe_f16<NF><<<256, 256>>>(out, cyc, iters);
+  hipDeviceSynchronize();
+  probe_f16<NF><<<256, 256>>>(out, cyc, iters);
+  hipDeviceSynchronize();
+  long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  printf("f16 32x32x16 MFMA, %d FMAs after each: %7.1f ticks per MFMA\n", NF, (double)c / iters / 24);
+}
+
 template <int MODE>
 void run(const char* name, float* out, long long* cyc, int iters, const float* src) {
   hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
@@ -121,5 +164,6 @@ int main() {
   run<5>("regs + 4 global dwordx4 per chunk", out, cyc, iters, src);
   run<7>("regs + 128 FMAs, 2 after every MFMA", out, cyc, iters, src);
   run<8>("regs + 128 FMAs in one burst", out, cyc, iters, src);
+  run_f16<0>(out, cyc, iters); run_f16<2>(out, cyc, iters); run_f16<4>(out, cyc, iters); run_f16<6>(out, cyc, iters); run_f16<8>(out, cyc, iters);
   return 0;
 }
