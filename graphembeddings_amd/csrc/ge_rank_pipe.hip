@@ -793,7 +793,7 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
     return launch_status();
   };
 #define GE_F16(DD)                                                                                     \
-  if (d == DD) {                                                                                       \
+  if (d == DD && max_norm <= 8.f) {   /* |q| <= 2 max_norm^2, |t clip| <= max_norm: x 2^8 stays inside fp16 */ \
     if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, DD>, f16_lds_bytes<DD>());                 \
     if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, DD>, f16_lds_bytes<DD>());                  \
     return go16(rank_pipe_kernel<CW, 0, 0, DD>, f16_lds_bytes<DD>());                                  \
