@@ -691,27 +691,25 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
           });
           if (lane < 32) { mrow[lane * 4] = (unsigned)M0; mrow[lane * 4 + 1] = (unsigned)M1; }
         } else {
-          // Per score: a multiply, "x < lo" (the bit, as a wave mask -> two v_writelane) and "x <= hi".  Both
-          // outcomes are also shifted into per-lane bitmaps (one v_addc each); they differ exactly where a score
-          // sits inside a bracket.  No scalar-unit work: SALU chains on compare results stall the wave.
-          unsigned L0 = 0, L1 = 0, H0 = 0, H1 = 0;               // four independent chains
+          // Per score: a multiply, "x < lo" (the bit, as a wave mask -> two v_writelane) and "x <= hi"; the scores
+          // inside the bracket (le and not lt: one scalar and-not) are shifted into a per-lane bitmap (one v_addc).
+          // Longer scalar chains on compare results (compare / select / or per score) stall the wave: measured.
+          unsigned I0 = 0, I1 = 0;                               // per-lane bitmaps of "inside the bracket"
           static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
             const float2 br = lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh];
             // (split-precision sweep: the candidate planes already carry the clip scale)
             const float x0 = F16 ? acc[tm][0][q] : acc[tm][0][q] * sb0, x1 = F16 ? acc[tm][1][q] : acc[tm][1][q] * sb1;
             const unsigned long long lt0 = __ballot(x0 < br.x), lt1 = __ballot(x1 < br.x);
-            shift_in(L0, lt0);
-            shift_in(L1, lt1);
-            shift_in(H0, __ballot(x0 <= br.y));
-            shift_in(H1, __ballot(x1 <= br.y));
+            shift_in(I0, __ballot(x0 <= br.y) & ~lt0);            // one scalar and-not per score, no chain
+            shift_in(I1, __ballot(x1 <= br.y) & ~lt1);
             set_lane<R32>(M0, (unsigned)lt0);
             set_lane<R32 + 4>(M0, (unsigned)(lt0 >> 32));
             set_lane<R32>(M1, (unsigned)lt1);
             set_lane<R32 + 4>(M1, (unsigned)(lt1 >> 32));
           });
           if (lane < 32) { mrow[lane * 4] = (unsigned)M0; mrow[lane * 4 + 1] = (unsigned)M1; }
-          const unsigned in0 = H0 ^ L0, in1 = H1 ^ L1;           // score (q, tn) of this lane: bit 15 - q of in<tn>
+          const unsigned in0 = I0, in1 = I1;                     // score (q, tn) of this lane: bit 15 - q of in<tn>
           if (in0 | in1) {                                       // lanes owning a score inside a bracket: the exact
             static_for<0, 4>([&](auto gc) {                      // comparison, bit set in LDS; 8 scores per outer test
               constexpr int g4 = decltype(gc)::value;
