@@ -236,11 +236,11 @@ __device__ __forceinline__ void set_lane(int& m, unsigned v) {
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int D>
-struct FCfg {                           // D = embedding_dim, compiled for 64, 128 and 200
+struct FCfg {                           // D = embedding_dim, compiled for 64, 96, 128, 160, 192 and 200
   static constexpr int kKB = (D + 15) / 16;       // k blocks of 16 (the last zero padded)
   static constexpr int kChunks = (kKB + 1) / 2;   // staged chunks of two k blocks = register slots of 32 reals
   static constexpr int kSA = 16 * kKB + 8;        // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
-  static_assert(D % 8 == 0 && D >= 64 && D <= 224, "embedding_dim of the split-precision sweep");
+  static_assert(D % 8 == 0 && D >= 64 && D <= 208, "embedding_dim of the split-precision sweep (LDS: Q planes + chunks)");
 };
 constexpr int kSB = 32 + 8;             // halves per candidate chunk row
 constexpr float kQScale = 256.f;   // both operands: |q|, |t * clip| <= 1
@@ -796,8 +796,8 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
     if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, DD>, f16_lds_bytes<DD>());                  \
     return go16(rank_pipe_kernel<CW, 0, 0, DD>, f16_lds_bytes<DD>());                                  \
   }
-  if constexpr (CW == 40) { GE_F16(200) }
-  if constexpr (CW == 32) { GE_F16(64) GE_F16(128) }
+  if constexpr (CW == 40) { GE_F16(200) GE_F16(160) }
+  if constexpr (CW == 32) { GE_F16(64) GE_F16(128) GE_F16(96) GE_F16(192) }
 #undef GE_F16
   if (scores_only) return (CW == 40 && d == 200) ? go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 2>) : go(rank_pipe_kernel<CW, 0, 2>);
   if (scores_out) return go(rank_pipe_kernel<CW, 0, 1>);

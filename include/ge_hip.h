@@ -208,7 +208,7 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * scores_out (nullable) [B,K] receives every loss -- for tests.  d must be a multiple of 8 and <= ge_rank_max_dim()
  * (the block's Q operand lives in LDS for the whole sweep), table 16-byte aligned; otherwise GE_ENOTSUP and the
  * caller falls back to ge_complex_score_1vK.
- * Arithmetic: fp32 MFMA with fp32 accumulation; for d = 64, 128, 200 and max_norm <= 8 the operands are split into
+ * Arithmetic: fp32 MFMA with fp32 accumulation; for d = 64, 96, 128, 160, 192, 200 and max_norm <= 8 the operands are split into
  * fp16 high halves and remainders (22 bits each, after the clip scales, so no fp16 overflow for any table) and
  * multiplied by three f16 MFMAs with fp32 accumulation -- losses within 1e-7 of the fp64 restatement either way
  * (ge_complex_score_1vK takes the same route for large sweeps at those dims). */
