@@ -61,6 +61,7 @@ SYMBOLS = {
     "ge_train_steps_logloss": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _i64, _i64, _p, _p, _i32, _p, _u64, _u64, _i32,
                                          _i32, _i32, _f, _f, _f, _f, _f, _p, C.c_int, _p, _p, _sz, _p, _p]),
     "ge_train_prepared_layout": (C.c_int, [_i64, C.POINTER(C.c_int64)]),
+    "ge_train_prepare_bytes": (_sz, [_i64, _i64]),
     "ge_train_prepare_steps": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _u64, _u64, _i32, _i32,
                                          C.c_int, _p, _sz, _p]),
     "ge_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),

@@ -38,6 +38,7 @@ size_t train_ws_bytes(int64_t, int32_t);
 int train_steps_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, float, float, float, float, float, int, float*, int, int32_t*, void*, size_t, void**, int, void*, hipStream_t);
 int train_prepare_run(const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int, int32_t*, hipStream_t);
 void train_prepared_layout(int64_t, int64_t*);
+size_t train_prepare_bytes(int64_t, int64_t);
 size_t train_logloss_ws_bytes(int64_t, int32_t, int32_t);
 int train_logloss_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t, float, float, float, float, float, float*, int, int32_t*, void*, size_t, void*, hipStream_t);
 int pipeline_create(void**);
@@ -368,6 +369,8 @@ int ge_train_prepared_layout(int64_t B, int64_t* out8) {
   return 0;
 }
 
+size_t ge_train_prepare_bytes(int64_t B, int64_t n_steps) { return (B <= 0 || n_steps <= 0) ? 0 : train_prepare_bytes(B, n_steps); }
+
 int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t n_steps,
                            const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
                            const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
@@ -375,9 +378,7 @@ int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row,
   if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || N <= 0) return GE_EINVAL;
   if (!triples || !id_to_type || !type_offsets || !type_ids || !out) return GE_EINVAL;
   if (mode < 0 || mode > 3 || padded_size < 0 || n_types < 0) return GE_EINVAL;
-  int64_t lay[8];
-  train_prepared_layout(B, lay);
-  if (out_bytes < sizeof(int32_t) * (size_t)n_steps * (size_t)lay[0]) return GE_ENOMEM;
+  if (out_bytes < train_prepare_bytes(B, n_steps)) return GE_ENOMEM;
   return train_prepare_run(triples, T, first_row, B, n_steps, id_to_type, N, type_offsets, n_types, type_ids, seed,
                            global_step0, padded_size, mode, direct, out, (hipStream_t)stream);
 }

@@ -1,0 +1,284 @@
+// ge_prep_big.hip -- the prepare stage of ge_train_steps / ge_train_steps_logloss for steps of MORE than
+// 4096 units (holE.py:340-362 at large batch_size): the step's (row, slot) keys no longer fit one
+// workgroup's LDS, so the stable LSD radix sort runs across workgroups:
+//
+//   prep_big_keys_kernel     grid (steps, tiles): negatives (holE.py:97-140, 343-347) + the <= 4 sort keys
+//                            of every unit, in slot order, to a global key array of tiles x P positions
+//   per radix pass           prep_big_hist_kernel     digit counts of every tile
+//                            prep_big_scatter_kernel  ranks inside the tile by the wave-level multisplit of
+//                                                     train_prepare_kernel (ballot ranks + per-wave digit
+//                                                     counters), global position = digits below + same digit
+//                                                     in earlier tiles + earlier waves of this tile + rank
+//   prep_big_items_kernel    grid (steps, tiles): the sorted tile back into LDS, cut into work items of
+//                            <= 16 slots of one row exactly like the one-tile kernel; runs that cross a tile
+//                            boundary are followed through global memory (an item belongs to the tile it
+//                            starts in), so the update stays ONE plain read-modify-write per distinct row
+//                            at any batch size -- no float atomics between tiles.
+//
+// Everything is integer work off the training stream's critical path (the look-ahead pipeline runs it on
+// the side stream one chunk of steps ahead).
+#include "ge_prep.h"
+
+namespace ge {
+
+// ---------------------------------------------------------------- keys
+__global__ __launch_bounds__(kPrepThreads) void prep_big_keys_kernel(
+    const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0,
+    const int32_t* __restrict__ id_to_type, int64_t N, const int64_t* __restrict__ type_offsets,
+    int32_t n_types, const int32_t* __restrict__ type_ids, uint64_t seed, uint64_t global_step0,
+    int32_t padded_size, int32_t mode, int direct, int negs, int32_t* __restrict__ prep,
+    unsigned long long* __restrict__ keys_out) {
+  const PrepLayout L = prep_layout(B, negs);
+  const int tid = threadIdx.x, sub = blockIdx.y;
+  const int64_t s = s0 + blockIdx.x;
+  int32_t* rec = prep + (int64_t)blockIdx.x * L.stride;
+  int32_t* slot_item = rec + L.off_slot;
+  const int64_t i0 = (int64_t)sub * kSub;
+  const int S = (int)((L.units - i0) < kSub ? (L.units - i0) : kSub);     // units of this tile
+  StepSource src{triples + 3 * step_row(first_row, T, B, s), B, id_to_type, N, type_offsets, n_types, type_ids, seed,
+                 global_step0 + (uint64_t)s, padded_size, mode, negs};
+  const bool batch_heads = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, src.step) : false;
+  unsigned long long* out = keys_out + ((int64_t)blockIdx.x * L.n_sub + sub) * L.P;
+  if (direct)
+    for (int i = tid; i < 6 * S; i += kPrepThreads) slot_item[6 * i0 + i] = -1;
+  for (int il = tid; il < (int)L.S; il += kPrepThreads) {
+    unsigned long long k[4] = {kInvalidKey, kInvalidKey, kInvalidKey, kInvalidKey};
+    if (il < S) unit_keys(src, i0 + il, batch_heads, rec, k);
+#pragma unroll
+    for (int X = 0; X < 4; ++X)
+      if (X < L.epu) out[L.epu * il + X] = k[X];
+  }
+}
+
+// ---------------------------------------------------------------- one radix pass
+// hist[(step * radix + digit) * n_sub + tile]
+__global__ __launch_bounds__(kPrepThreads) void prep_big_hist_kernel(
+    const unsigned long long* __restrict__ src, int P, int n_sub, int shift, int bits, unsigned* __restrict__ hist) {
+  __shared__ unsigned cnt[kMaxRadix];
+  const int tid = threadIdx.x, tile = blockIdx.y;
+  const int radix = 1 << bits;
+  const unsigned dmask = (unsigned)radix - 1u;
+  if (tid < radix) cnt[tid] = 0;
+  __syncthreads();
+  const unsigned long long* k = src + ((int64_t)blockIdx.x * n_sub + tile) * P;
+  for (int i = tid; i < P; i += kPrepThreads) atomicAdd(&cnt[(unsigned)(k[i] >> shift) & dmask], 1u);
+  __syncthreads();
+  if (tid < radix) hist[((int64_t)blockIdx.x * radix + tid) * n_sub + tile] = cnt[tid];
+}
+
+__global__ __launch_bounds__(kPrepThreads) void prep_big_scatter_kernel(
+    const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+    const unsigned* __restrict__ hist, int P, int n_sub, int shift, int bits) {
+  __shared__ unsigned whist[kMaxRadix * kPrepWaves];   // (digit, wave) counters of this tile
+  __shared__ unsigned gbase[kMaxRadix];                // first global position of (digit, this tile)
+  __shared__ unsigned wsum[4];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, tile = blockIdx.y;
+  const int radix = 1 << bits, R = P / kPrepThreads, seg = kWave * R;
+  const unsigned dmask = (unsigned)radix - 1u;
+  const unsigned* h = hist + (int64_t)blockIdx.x * radix * n_sub;
+  // keys with a smaller digit anywhere + the same digit in earlier tiles
+  unsigned tot = 0, before = 0;
+  if (tid < radix)
+    for (int q = 0; q < n_sub; ++q) { const unsigned v = h[tid * n_sub + q]; if (q < tile) before += v; tot += v; }
+  int incl = 0;
+  if (tid < kMaxRadix) {
+    incl = wave_incl_add((int)tot, lane);
+    if (lane == kWave - 1) wsum[wave] = (unsigned)incl;
+  }
+  for (int i = tid; i < radix * kPrepWaves; i += kPrepThreads) whist[i] = 0;
+  __syncthreads();
+  if (tid < radix) {
+    unsigned run = (unsigned)incl - tot;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    gbase[tid] = run + before;
+  }
+  // ranks inside the tile: wave w owns positions [w*seg, (w+1)*seg), round r holds w*seg + r*64 + lane
+  const unsigned long long* kin = src + ((int64_t)blockIdx.x * n_sub + tile) * P;
+  unsigned long long k[16];
+  unsigned off[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (r < R) k[r] = kin[wave * seg + r * kWave + lane];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < R) {
+      const unsigned dg = (unsigned)(k[r] >> shift) & dmask;
+      unsigned long long peers = ~0ull;
+      for (int b = 0; b < bits; ++b) {
+        const bool bit = (dg >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+      }
+      const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+      const unsigned cnt = (unsigned)__popcll(peers);
+      unsigned* hp = whist + dg * kPrepWaves + wave;
+      const unsigned base = *hp;                       // same value for every peer ...
+      __builtin_amdgcn_wave_barrier();
+      if (rank == 0) *hp = base + cnt;                 // ... then the lowest peer advances the counter
+      __builtin_amdgcn_wave_barrier();
+      off[r] = base + rank;
+    }
+  }
+  __syncthreads();
+  if (tid < radix) {                                   // same digit in earlier waves of this tile
+    unsigned run = 0;
+    for (int w = 0; w < kPrepWaves; ++w) { const unsigned c = whist[tid * kPrepWaves + w]; whist[tid * kPrepWaves + w] = run; run += c; }
+  }
+  __syncthreads();
+  unsigned long long* out = dst + (int64_t)blockIdx.x * n_sub * P;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < R) {
+      const unsigned dg = (unsigned)(k[r] >> shift) & dmask;
+      out[gbase[dg] + whist[dg * kPrepWaves + wave] + off[r]] = k[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- work items of one sorted tile
+// LDS: keys[P] | wtot[32] | rs_in.  Positions are GLOBAL (tile * P + i) so that runs continue across tiles.
+__global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
+    const unsigned long long* __restrict__ sorted, int64_t B, int negs, int direct, int32_t* __restrict__ prep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const PrepLayout L = prep_layout(B, negs);
+  const int P = (int)L.P, R = P / kPrepThreads, seg = kWave * R, n_sub = (int)L.n_sub;
+  int* wtot = reinterpret_cast<int*>(keys + P);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, tile = blockIdx.y;
+  const unsigned long long* g = sorted + (int64_t)blockIdx.x * n_sub * P;
+  const int total = n_sub * P, base = tile * P;
+  int32_t* rec = prep + (int64_t)blockIdx.x * L.stride;
+  int32_t* slot_item = rec + L.off_slot;
+  int32_t* subrec = rec + L.off_sub + tile * L.sub_stride;
+  int32_t* items = subrec + L.off_items;
+  int32_t* islots = subrec + L.off_islots;
+  for (int i = tid; i < P; i += kPrepThreads) keys[i] = g[base + i];
+  if (tid == 0) {
+    // a run that began in an earlier tile: its first position, by binary search over the sorted sequence
+    int rs = -1;
+    if (tile > 0) {
+      const unsigned long long k0 = g[base], kp = g[base - 1];
+      const uint32_t r0 = (uint32_t)(k0 >> 32);
+      if (k0 != kInvalidKey && (uint32_t)(kp >> 32) == r0) {
+        int lo = 0, hi = base - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)(g[mid] >> 32) < r0) lo = mid + 1; else hi = mid; }
+        rs = lo;
+      }
+    }
+    wtot[31] = rs;
+  }
+  __syncthreads();
+  const int rs_in = wtot[31];
+  // i is tile-relative and may leave [0, P): the neighbours come from global memory
+  auto key_at = [&](int i) -> unsigned long long {
+    if (i >= 0 && i < P) return keys[i];
+    const int gi = base + i;
+    return (gi >= 0 && gi < total) ? g[gi] : kInvalidKey;
+  };
+  // (a) run start (global position) of every position: max-scan of head positions
+  {
+    int carry = -1;
+    for (int r = 0; r < R; ++r) {
+      const int i = wave * seg + r * kWave + lane;
+      const unsigned long long kk = keys[i], kp = key_at(i - 1);
+      const bool head = kk != kInvalidKey && (base + i == 0 || (uint32_t)(kp >> 32) != (uint32_t)(kk >> 32));
+      const int m = max(wave_incl_max(head ? base + i : -1, lane), carry);
+      carry = __shfl(m, kWave - 1, kWave);
+    }
+    if (lane == 0) wtot[wave] = carry;
+  }
+  __syncthreads();
+  int prev_max = rs_in;
+  for (int w = 0; w < wave; ++w) prev_max = max(prev_max, wtot[w]);
+  __syncthreads();
+  // (b) item starts, counted
+  unsigned start_mask = 0;
+  int idx_loc[16], rs_loc[16];
+  {
+    int carry = 0, mcarry = prev_max;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r < R) {
+        const int i = wave * seg + r * kWave + lane;
+        const unsigned long long kk = keys[i], kp = key_at(i - 1), kn = key_at(i + 1);
+        const bool valid = kk != kInvalidKey;
+        const uint32_t row = (uint32_t)(kk >> 32);
+        const bool head = valid && (base + i == 0 || (uint32_t)(kp >> 32) != row);
+        const bool sole = direct && head && !(kn != kInvalidKey && (uint32_t)(kn >> 32) == row);
+        const int rs = max(wave_incl_max(head ? base + i : -1, lane), mcarry);
+        mcarry = __shfl(rs, kWave - 1, kWave);
+        rs_loc[r] = rs;
+        const bool start = valid && ((base + i - rs) % kItemCap) == 0 && !sole;
+        if (start) start_mask |= 1u << r;
+        if (sole) slot_item[(uint32_t)kk] = kSlotDirect;
+        const int incl = wave_incl_add(start ? 1 : 0, lane) + carry;
+        idx_loc[r] = incl - (start ? 1 : 0);
+        carry = __shfl(incl, kWave - 1, kWave);
+      }
+    }
+    if (lane == 0) wtot[wave] = carry;
+  }
+  __syncthreads();
+  int prev_items = 0, n_items = 0;
+  for (int w = 0; w < kPrepWaves; ++w) { if (w < wave) prev_items += wtot[w]; n_items += wtot[w]; }
+  if (tid == 0) subrec[0] = n_items;
+  // (c) emit
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (r < R && ((start_mask >> r) & 1u)) {
+      const int i = wave * seg + r * kWave + lane;
+      const uint32_t row = (uint32_t)(keys[i] >> 32);
+      const int idx = prev_items + idx_loc[r];
+      int e = i + 1;
+      unsigned long long ke = key_at(e);
+      while ((e - i) < kItemCap && ke != kInvalidKey && (uint32_t)(ke >> 32) == row) { ++e; ke = key_at(e); }
+      const bool more = ke != kInvalidKey && (uint32_t)(ke >> 32) == row;
+      const bool multi = (base + i != rs_loc[r]) || more;
+      items[2 * idx] = (int32_t)row;
+      items[2 * idx + 1] = (e - i) | (multi ? (1 << 30) : 0);
+#pragma unroll
+      for (int j = 0; j < kItemCap; ++j)
+        islots[idx * kItemCap + j] = (i + j < e) ? (int32_t)(uint32_t)key_at(i + j) : -1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host
+static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// scratch of one prepare sequence over n steps: two key arrays (ping-pong) + the digit counts of one pass
+size_t prep_big_scratch_bytes(int64_t B, int64_t negs, int64_t n) {
+  const PrepLayout L = prep_layout(B, negs);
+  if (L.n_sub <= 1) return 0;
+  const size_t keys = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)L.n_sub * (size_t)L.P, 256);
+  const size_t hist = align_up_sz(sizeof(unsigned) * (size_t)n * kMaxRadix * (size_t)L.n_sub, 256);
+  return 2 * keys + hist;
+}
+
+int prepare_big_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n,
+                       const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
+                       const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
+                       int32_t mode, int direct, int32_t* out, void* scratch, hipStream_t st, int negs) {
+  const PrepLayout L = prep_layout(B, negs);
+  const SortBits sb = sort_bits_for(N);
+  const size_t keys_bytes = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)L.n_sub * (size_t)L.P, 256);
+  unsigned long long* ka = reinterpret_cast<unsigned long long*>(scratch);
+  unsigned long long* kb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + keys_bytes);
+  unsigned* hist = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + 2 * keys_bytes);
+  const dim3 grid((unsigned)n, (unsigned)L.n_sub), block(kPrepThreads);
+  hipLaunchKernelGGL(prep_big_keys_kernel, grid, block, 0, st, triples, T, first_row, B, s0, id_to_type, N, type_offsets,
+                     n_types, type_ids, seed, global_step0, padded_size, mode, direct, negs, out, ka);
+  for (int pass = 0; pass < sb.n_pass; ++pass) {
+    const int shift = 32 + pass * sb.bits;
+    hipLaunchKernelGGL(prep_big_hist_kernel, grid, block, 0, st, ka, (int)L.P, (int)L.n_sub, shift, sb.bits, hist);
+    hipLaunchKernelGGL(prep_big_scatter_kernel, grid, block, 0, st, ka, kb, hist, (int)L.P, (int)L.n_sub, shift, sb.bits);
+    unsigned long long* t = ka; ka = kb; kb = t;
+  }
+  const size_t lds = sizeof(unsigned long long) * (size_t)L.P + sizeof(int) * 32;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prep_big_items_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(prep_big_items_kernel, grid, block, lds, st, ka, B, negs, direct, out);
+  return launch_status();
+}
+
+}  // namespace ge

@@ -3,12 +3,13 @@
 // Negatives depend only on (seed, step, positives) -- never on the table -- so everything about a
 // step except its floating-point work can be prepared ahead, in bulk, for a chunk of steps:
 //
-//   train_prepare_kernel   one 1024-thread workgroup per (step, sub-batch of <= 4096 pairs): draws the
+//   train_prepare_kernel   one 1024-thread workgroup per step of <= 4096 units: draws the
 //                          negatives (holE.py:97-140, 343-347), builds the (row, IndexedSlices slot)
 //                          list of the <= 4 gradient rows per pair, sorts it by row with a stable LSD
 //                          radix sort held entirely in LDS (wave-level multisplit: ballot ranks +
 //                          per-wave digit counters, 2 passes for FB15k's 16,296 rows, 3 for 1.2 M rows)
-//                          and cuts it into work items of <= 16 slots of one row.
+//                          and cuts it into work items of <= 16 slots of one row.  Larger steps: the
+//                          same sort across workgroups, ge_prep_big.hip.
 //   (per step) hinge_grad  fused gather -> clip -> score -> sigmoid -> hinge -> gradient rows
 //   (per step) apply_sorted_kernel   one wavefront per work item sums its gradient rows and
 //                          updates the table row ONCE with a plain read-modify-write.
@@ -16,16 +17,15 @@
 // This replaces the float-atomic ScatterSub (memory-side atomics ~1.3 TB/s chip-wide and an order
 // of magnitude slower when many waves hit one hot row -- Zipfian heads, a handful of relations)
 // by coalesced row reads plus one write per distinct row, and makes the update order fixed:
-// rows with <= 16 occurrences (the vast majority) are bitwise reproducible for B <= 4096.  Only rows
-// split over several work items (and, for B > 4096, rows shared by several sub-batches) combine their
-// partial sums with atomics.
+// rows with <= 16 occurrences in a step (the vast majority) are bitwise reproducible at any batch size.
+// Only rows split over several work items combine their partial sums with atomics.
 //
 // The prepared records live in the caller's workspace, two chunks of steps (double buffer).  With a
 // pipeline handle (ge_train_pipeline_create) the prepare launches run on the handle's side stream one
 // chunk AHEAD of the steps that consume them -- across ge_train_steps calls too: a call that continues
 // where the previous one stopped finds its records already built.  Without a handle the launches go
 // to the caller's stream (one ~20 us launch per chunk of steps) and the library keeps no state at all.
-#include "ge_common.h"
+#include "ge_prep.h"
 #include <cmath>
 
 namespace ge {
@@ -35,67 +35,8 @@ int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int hole_spectral_launch(float*, int64_t, int32_t, int, hipStream_t);
-
-constexpr int kSlotDirect = -2;  // slot_item code: sole contributor of its row, applied by the producer
-constexpr int kPrepThreads = 1024;
-constexpr int kPrepWaves = kPrepThreads / kWave;
-constexpr int kItemCap = 16;       // C: max gradient rows summed by one wavefront
-constexpr int64_t kSub = 4096;     // pairs sorted by one workgroup: 4 x 4096 keys of 8 B = 128 KiB of the CU's 160 KiB
-constexpr int kMaxRadix = 256;
-
-__host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_t B, int64_t s) {
-  // batch s starts at first_row + s*B, wrapping to row 0 whenever a batch would run past T
-  // (no short batches, holE.py:283)
-  int64_t first = first_row % T;
-  if (first + B > T) first = 0;
-  const int64_t n0 = (T - first) / B;  // steps before the first wrap
-  if (s < n0) return first + s * B;
-  const int64_t per = T / B;
-  return ((s - n0) % per) * B;
-}
-
-// ------------------------------------------------------------------ prepared-step record (int32 words)
-// hinge (negs = 0):   neg[3B] | slot_item[6B] | pad to 64 | n_sub x { n_items, pad to 64 | items[P][2] | islots[P][16] }
-//   a UNIT is a (pos,neg) pair with 4 sort keys; slot = 6*pair + {0 h+,1 t+,2 r+,3 h-,4 t-,5 r-}.
-// log-loss (negs = K): neg[K][B][3] | pad to 64 | n_sub x { ... }
-//   a UNIT is one of the M = (1+K)B triples (positives first, then the K corrupted batches, holE.py:206-220)
-//   with 3 sort keys; slot = 3*triple + {0 h, 1 t, 2 r}.
-// S = units per sub-batch (<= 4096), P = keys per sub-batch (a multiple of 1024).  items[k] = {table row,
-// count | multi << 30}; islots[k][0..16) = the slots the item sums, -1 padded.
-struct PrepLayout {
-  int64_t B, negs, units, n_sub, S, P, off_slot, off_sub, sub_stride, off_items, off_islots, stride;
-  int epu;   // sort keys per unit
-};
-__host__ __device__ inline PrepLayout prep_layout(int64_t B, int64_t negs = 0) {
-  PrepLayout L;
-  L.B = B;
-  L.negs = negs;
-  L.epu = negs > 0 ? 3 : 4;
-  L.units = negs > 0 ? (1 + negs) * B : B;
-  L.n_sub = (L.units + kSub - 1) / kSub;
-  const int64_t s = L.units < kSub ? L.units : kSub;
-  const int64_t gran = negs > 0 ? 1024 : 256;          // P = epu * S must be a multiple of 1024
-  L.S = (s + gran - 1) / gran * gran;
-  L.P = L.epu * L.S;
-  L.off_slot = 3 * B;
-  L.off_sub = negs > 0 ? (3 * negs * B + 63) / 64 * 64 : (9 * B + 63) / 64 * 64;
-  L.off_items = 64;
-  L.off_islots = 64 + 2 * L.P;
-  L.sub_stride = 64 + 2 * L.P + kItemCap * L.P;
-  L.stride = L.off_sub + L.n_sub * L.sub_stride;
-  return L;
-}
-
-__device__ __forceinline__ int wave_incl_add(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(v, o, kWave); if (lane >= o) v += t; }
-  return v;
-}
-__device__ __forceinline__ int wave_incl_max(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(v, o, kWave); if (lane >= o) v = max(v, t); }
-  return v;
-}
+size_t prep_big_scratch_bytes(int64_t B, int64_t negs, int64_t n);
+int prepare_big_launch(const int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int, int32_t*, void*, hipStream_t, int);
 
 // grid (steps in the chunk, n_sub).  LDS: keys[P] (8 B) | hist[16 waves x 256 digits] | wtot[32].
 __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
@@ -128,57 +69,18 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
     for (int i = tid; i < 6 * S; i += kPrepThreads) slot_item[6 * i0 + i] = -1;
 
   // ---- phase 1: negatives + sort keys, in slot order (key index epu*unit + k  <->  ascending slot id)
-  if (negs > 0) {
-    // log-loss: unit j < B is positive j; unit B + k*B + i is positive i corrupted by the k-th corrupt_batch
-    // call of the step, whose Philox step key is global_step * K + k (its own coin, its own subsample)
+  {
+    const StepSource src{pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, step, padded_size, mode, negs};
     for (int il = tid; il < (int)L.S; il += kPrepThreads) {
-      unsigned long long k3[3] = {kInvalid, kInvalid, kInvalid};
-      if (il < S) {
-        const int64_t j = i0 + il;
-        const int64_t i = j < B ? j : (j - B) % B;
-        int32_t t3[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-        if (j >= B) {
-          const int64_t kk = (j - B) / B;
-          const uint64_t stepk = step * (uint64_t)negs + (uint64_t)kk;
-          const bool heads_k = (mode == GE_CORRUPT_BATCH_COIN) ? batch_coin_heads(seed, stepk) : false;
-          int col;
-          const int32_t repl = corrupt_one(t3, i, heads_k, id_to_type, N, type_offsets, n_types, type_ids, seed, stepk,
-                                           padded_size, mode, col);
-          t3[col] = repl;
-          int32_t* o = neg + 3 * (kk * B + i);
-          o[0] = t3[0]; o[1] = t3[1]; o[2] = t3[2];
-        }
-        const bool bad = t3[0] < 0 || t3[1] < 0 || t3[2] < 0 || t3[0] >= N || t3[1] >= N || t3[2] >= N;
+      unsigned long long k4[4] = {kInvalid, kInvalid, kInvalid, kInvalid};
+      if (il < S) unit_keys(src, i0 + il, batch_heads, neg, k4);
+      if (negs > 0) {
 #pragma unroll
-        for (int X = 0; X < 3; ++X)
-          if (!bad) k3[X] = ((unsigned long long)(uint32_t)t3[X] << 32) | (uint32_t)(3 * j + X);
+        for (int X = 0; X < 3; ++X) keys[3 * il + X] = k4[X];
+      } else {
+#pragma unroll
+        for (int X = 0; X < 4; ++X) keys[4 * il + X] = k4[X];
       }
-#pragma unroll
-      for (int X = 0; X < 3; ++X) keys[3 * il + X] = k3[X];
-    }
-  } else
-  for (int il = tid; il < (int)L.S; il += kPrepThreads) {
-    if (il < S) {
-      const int64_t i = i0 + il;
-      int32_t p[3] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-      int col;
-      const int32_t repl = corrupt_one(p, i, batch_heads, id_to_type, N, type_offsets, n_types, type_ids,
-                                       seed, step, padded_size, mode, col);
-      int32_t n[3] = {p[0], p[1], p[2]};
-      n[col] = repl;
-      neg[3 * i] = n[0]; neg[3 * i + 1] = n[1]; neg[3 * i + 2] = n[2];
-      const bool bad = p[0] < 0 || p[1] < 0 || p[2] < 0 || p[0] >= N || p[1] >= N || p[2] >= N ||
-                       repl < 0 || repl >= N;
-      // IndexedSlices slots of pair i (ge_hip.h): h+ 0, t+ 1, r+ 2, h- 3, t- 4, r- 5; a negative-side
-      // slot exists only where the row differs from the positive one.
-#pragma unroll
-      for (int X = 0; X < 3; ++X)
-        keys[4 * il + X] = bad ? kInvalid : (((unsigned long long)(uint32_t)p[X] << 32) | (uint32_t)(6 * i + X));
-      keys[4 * il + 3] = (bad || repl == p[col]) ? kInvalid
-                                                 : (((unsigned long long)(uint32_t)repl << 32) | (uint32_t)(6 * i + 3 + col));
-    } else {
-#pragma unroll
-      for (int X = 0; X < 4; ++X) keys[4 * il + X] = kInvalid;
     }
   }
   __syncthreads();
@@ -316,9 +218,10 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
 
 // One wavefront per work item: sum the item's gradient rows (skipping slots whose pair was
 // hinge-inactive: grad_idx < 0), then table[row] += sum -- plain RMW when the row has a single
-// item, atomics when it was split (or when the step has several sub-batches, blockIdx.y, whose items
-// may share rows).  Lane l owns columns l, l+64, ... (256 contiguous bytes per wave instruction for
-// loads, stores and atomics alike).
+// item, atomics when it was split over several (> 16 slots).  blockIdx.y = tile of the step's sorted key
+// sequence; tiles never share a single-item row (the sort is over the whole step, ge_prep_big.hip).
+// Lane l owns columns l, l+64, ... (256 contiguous bytes per wave instruction for loads, stores and
+// atomics alike).
 template <int NJ>
 __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
@@ -329,14 +232,13 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
   const int32_t* subrec = sub0 + (int64_t)blockIdx.y * sub_stride;
   const int32_t* items = subrec + off_items;
   const int32_t* islots = subrec + off_islots;
-  const bool shared_rows = gridDim.y > 1;
   const int n_items = subrec[0];
   for (int w = wave; w < n_items; w += nwaves) {
     // two independent loads first: the item header and its inline slot list (lane o < 16 -> slot o)
     const int row = items[2 * w], cm = items[2 * w + 1];
     int slot_v = (lane < kItemCap) ? islots[w * kItemCap + lane] : -1;
     const int cnt = cm & 0x3FFFFFFF;
-    const bool multi = ((cm >> 30) & 1) || shared_rows;
+    const bool multi = (cm >> 30) & 1;
     float* dst = table + (int64_t)row * d;
     // the table row is fetched now, under the gradient-row loads, not after them
     float base[NJ];
@@ -408,12 +310,14 @@ size_t hinge_ws_bytes(int64_t B, int32_t d) {
 
 bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= (int64_t)1 << 24 && d <= 1024; }
 
-// steps prepared per launch: 32 at B <= 4096 (one record is ~1.2 MB there), fewer for large batches so
-// that a chunk stays near 40 MB
+// steps prepared per launch: 32 at B <= 4096 (one record is ~1.2 MB there), fewer for large batches
 static int64_t prep_chunk_steps(int64_t B, int64_t negs = 0) {
   const int64_t u = negs > 0 ? (1 + negs) * B : B;
   int64_t c = (32 * kSub) / (u < kSub ? kSub : u);
-  return c < 2 ? 2 : c;
+  // the multi-tile sort is a sequence of short launches (2 per radix pass): its latency is the same for 2 steps
+  // or 8, so a chunk holds at least 8 steps (19 MB of records each at B = 65,536) until records pass ~1 GB
+  const int64_t floor_steps = u <= 4 * 65536 ? 8 : 2;
+  return c < floor_steps ? floor_steps : c;
 }
 
 // training workspace: [gidx 6B][gval RING x (6B x d)][prep chunk buffer 0][prep chunk buffer 1].
@@ -443,7 +347,8 @@ static size_t prep_chunk_bytes(int64_t B, int64_t negs = 0) {
 }
 size_t train_ws_bytes(int64_t B, int32_t d) {
   if (!train_fast_ok(B, d)) return hinge_ws_bytes(B, d);
-  return train_grad_bytes(B, d) + 2 * prep_chunk_bytes(B);  // double-buffered
+  // two chunk buffers + (B > 4096) the key arrays of the multi-tile sort of ONE prepare sequence
+  return train_grad_bytes(B, d) + 2 * prep_chunk_bytes(B) + prep_big_scratch_bytes(B, 0, prep_chunk_steps(B));
 }
 
 static size_t prep_lds_bytes(const PrepLayout& L) {
@@ -453,13 +358,13 @@ static size_t prep_lds_bytes(const PrepLayout& L) {
 static int prepare_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n,
                           const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
                           const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
-                          int32_t mode, int direct, int32_t* out, hipStream_t st, int negs = 0) {
+                          int32_t mode, int direct, int32_t* out, void* scratch, hipStream_t st, int negs = 0) {
   const PrepLayout L = prep_layout(B, negs);
-  int nbits = 1;
-  while (((int64_t)1 << nbits) <= N) ++nbits;          // the value N itself (and above) is free for invalid keys
-  const int n_pass = (nbits + 7) / 8;
-  int bits = (nbits + n_pass - 1) / n_pass;
-  if (bits < 6) bits = 6;                              // >= 1024 counters: one per thread in the scan
+  if (L.n_sub > 1)   // more keys than one workgroup's LDS holds: the sort runs across workgroups
+    return prepare_big_launch(triples, T, first_row, B, s0, n, id_to_type, N, type_offsets, n_types, type_ids, seed,
+                              global_step0, padded_size, mode, direct, out, scratch, st, negs);
+  const SortBits sb = sort_bits_for(N);
+  const int n_pass = sb.n_pass, bits = sb.bits;
   const size_t lds = prep_lds_bytes(L);
   // per device, idempotent and cheap: no cached flag, so no state and nothing to get stale on a second device
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_prepare_kernel),
@@ -618,7 +523,7 @@ class PrepCursor {
     }
     int rc = prepare_launch(id_.triples, id_.T, pipe_->origin_row, id_.B, c * K_, K_, id_.id_to_type, id_.N,
                             id_.type_offsets, id_.n_types, id_.type_ids, id_.seed, pipe_->origin_gs, id_.padded_size,
-                            id_.mode, id_.direct, base_ + b * buf_ints_, pipe_->side, id_.negs);
+                            id_.mode, id_.direct, base_ + b * buf_ints_, base_ + 2 * buf_ints_, pipe_->side, id_.negs);
     if (rc) return rc;
     if (own_side_) GE_HIP_TRY(hipEventRecord(pipe_->prep_done[b], pipe_->side));
     pipe_->resident[b] = c;
@@ -658,7 +563,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
   const bool fast = train_fast_ok(B, d) && workspace_bytes >= train_ws_bytes(B, d);
   const int ring = fast ? grad_ring(B, d) : 1;
   const size_t region_floats = grad_region_bytes(B, d) / sizeof(float);
-  const int direct = (prep_layout(B).n_sub == 1 && !hole_direct) ? 1 : 0;   // sole-slot rows updated by the producing pair
+  const int direct = hole_direct ? 0 : 1;   // sole-slot rows updated by the producing pair
   const StepIdentity ident{triples, T, first_row, B, id_to_type, N, type_offsets, n_types, type_ids, seed, global_step0,
                            padded_size, mode, d, direct, 0, workspace};
   PrepCursor cur(ident, fast ? static_cast<Pipeline*>(pipe_handle) : nullptr,
@@ -732,7 +637,8 @@ size_t train_logloss_ws_bytes(int64_t B, int32_t negs, int32_t d) {
   size_t ring = ((size_t)64 << 20) / region + 1;
   if (ring < 2) ring = 2;
   if (ring > 8) ring = 8;
-  return 256 + align_up_sz(sizeof(int32_t) * 3 * M, 256) + ring * region + 2 * prep_chunk_bytes(B, negs);
+  return 256 + align_up_sz(sizeof(int32_t) * 3 * M, 256) + ring * region + 2 * prep_chunk_bytes(B, negs) +
+         prep_big_scratch_bytes(B, negs, prep_chunk_steps(B, negs));
 }
 
 int complex_logloss_grad_launch(const float*, int64_t, int32_t, const int32_t*, const float*, int64_t, float, float, float, const float*, float*, int32_t*, float*, hipStream_t, const int32_t*, int64_t, float, float, hipEvent_t, hipEvent_t);
@@ -813,18 +719,19 @@ int train_logloss_run(float* table, int64_t N, int32_t d, const int32_t* triples
   return 0;
 }
 
-// prepared records of `n_steps` consecutive steps into a caller buffer (tests, tools; the sharded
-// path's planner): the same launch ge_train_steps uses.
+// prepared records of `n_steps` consecutive steps into a caller buffer (tests, tools): the same launch
+// ge_train_steps uses.  For B > 4096 the buffer also holds the multi-tile sort's scratch, behind the records.
+size_t train_prepare_bytes(int64_t B, int64_t n_steps) {
+  return align_up_sz(sizeof(int32_t) * (size_t)n_steps * (size_t)prep_layout(B).stride, 256) + prep_big_scratch_bytes(B, 0, n_steps);
+}
 int train_prepare_run(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t n_steps,
                       const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,
                       const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
                       int32_t mode, int direct, int32_t* out, hipStream_t st) {
   if (n_steps == 0) return 0;
-  const PrepLayout L = prep_layout(B);
-  if (!direct || L.n_sub == 1)
-    return prepare_launch(triples, T, norm_row(first_row, T, B), B, 0, n_steps, id_to_type, N, type_offsets, n_types,
-                          type_ids, seed, global_step0, padded_size, mode, direct ? 1 : 0, out, st);
-  return GE_EINVAL;   // direct tagging needs the whole step in one sub-batch
+  void* scratch = reinterpret_cast<char*>(out) + align_up_sz(sizeof(int32_t) * (size_t)n_steps * (size_t)prep_layout(B).stride, 256);
+  return prepare_launch(triples, T, norm_row(first_row, T, B), B, 0, n_steps, id_to_type, N, type_offsets, n_types,
+                        type_ids, seed, global_step0, padded_size, mode, direct ? 1 : 0, out, scratch, st);
 }
 
 void train_prepared_layout(int64_t B, int64_t* out) {

@@ -677,12 +677,14 @@ def prepare_steps(triples: torch.Tensor, type_tables: TypeTables, batch_size: in
     row-sorted work items of `n_steps` consecutive steps as an int32 [n_steps, words] tensor."""
     tb = _triples(triples, "triples")
     lay = prepared_layout(batch_size)
-    out = torch.empty(n_steps, lay[0], dtype=torch.int32, device=tb.device)
+    nbytes = int(_lib.load().ge_train_prepare_bytes(int(batch_size), int(n_steps)))   # records + (B > 4096) sort scratch
+    buf = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=tb.device)
+    out = buf[:n_steps * lay[0]].view(n_steps, lay[0])
     tt = type_tables
     _lib.call("ge_train_prepare_steps", tb.data_ptr(), tb.shape[0], int(first_row), int(batch_size), int(n_steps),
               tt.id_to_type.data_ptr(), tt.id_to_type.numel(), tt.type_offsets.data_ptr(), tt.n_types,
               tt.type_ids.data_ptr(), int(seed) & (2**64 - 1), int(global_step), tt.padded_size, int(mode),
-              int(bool(direct)), out.data_ptr(), out.numel() * 4, _stream())
+              int(bool(direct)), buf.data_ptr(), buf.numel() * 4, _stream())
     return out
 
 

@@ -270,8 +270,8 @@ int ge_plan_items(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, 
  * row-sorted index of the step's gradient slots are built ahead of time, for a chunk of steps per
  * launch (one workgroup per step and per sub-batch of 4096 pairs: sampler + stable LDS radix sort by
  * row), into two chunk buffers inside the workspace.  The update then touches every distinct row
- * once, with plain read-modify-writes (float atomics only for rows with > 16 gradient slots in a
- * step and, when B > 4096, for all rows: sub-batches may share rows).  The workspace also holds a
+ * once, with plain read-modify-writes at any B (float atomics only for rows with > 16 gradient slots in a
+ * step; for B > 4096 the sort runs across workgroups, csrc/ge_prep_big.hip).  The workspace also holds a
  * ring of gradient-row regions, one per step in turn.  With only ge_hinge_step_workspace_bytes the
  * loop falls back to sampler + float-atomic scatter per step.
  *
@@ -332,13 +332,17 @@ int ge_train_steps_logloss(float* table, int64_t N, int32_t d, const int32_t* tr
                            int32_t* neg_ws, void* workspace, size_t workspace_bytes, void* pipeline, void* stream);
 
 /* The prepare launch on its own: the records of n_steps consecutive steps, as ge_train_steps builds
- * them, into `out` (>= n_steps * layout[0] int32 words).  ge_train_prepared_layout fills out8 =
- * {words per step record, sub-batches per step, pairs per sub-batch S, offset of slot_item[6B],
- * offset of sub-batch 0, words per sub-batch, offset of items inside a sub-batch, offset of islots}.
- * A step record is  neg[3B] | slot_item[6B] | sub-batches { n_items, pad | items[4S][2] = {table row,
+ * them, into `out` (ge_train_prepare_bytes(B, n_steps) bytes: n_steps * layout[0] int32 words of records,
+ * then -- for B > 4096 -- the key arrays of the multi-workgroup sort).  ge_train_prepared_layout fills out8 =
+ * {words per step record, tiles per step, pairs per tile S, offset of slot_item[6B],
+ * offset of tile 0, words per tile, offset of items inside a tile, offset of islots}.
+ * A step record is  neg[3B] | slot_item[6B] | tiles { n_items, pad | items[4S][2] = {table row,
  * count | multi << 30} | islots[4S][16] = the IndexedSlices slots (6*pair + k) an item sums, -1 padded }.
- * direct = 1 (needs B <= 4096): a row with exactly one gradient slot in the step is not queued as an
+ * The step's (row, slot) keys are sorted as one sequence of tiles * 4S positions; tile t lists the items that
+ * start in positions [t*4S, (t+1)*4S).
+ * direct = 1: a row with exactly one gradient slot in the step is not queued as an
  * item; its slot is tagged -2 in slot_item and the pair that produces it updates the table row. */
+size_t ge_train_prepare_bytes(int64_t B, int64_t n_steps);
 int ge_train_prepared_layout(int64_t B, int64_t* out8);
 int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t n_steps,
                            const int32_t* id_to_type, int64_t N, const int64_t* type_offsets, int32_t n_types,

@@ -617,11 +617,13 @@ def test_train_steps_match_c_port_step_by_step(H, model, B, d, steps):
     assert np.array_equal(tr._neg.cpu().numpy(), neg)
 
 
-def test_train_steps_fast_path_is_reproducible(H):
+@pytest.mark.parametrize("B", [2048, 8192, 20000])
+def test_train_steps_fast_path_is_reproducible(H, B):
     """Two runs from the same state give bitwise-identical tables on rows with <= 16 occurrences
-    per step (here: uniform ids, so every row)."""
+    per step (here: uniform ids, so every row) -- also when the step's keys are sorted across several
+    workgroups (B = 8192: two tiles; B = 20000: five, the last one partial)."""
     rng = np.random.default_rng(0)
-    N, d, B, T = 50000, 200, 2048, 40000
+    N, d, T = 50000, 200, 90000
     tri = np.stack([rng.integers(10, N, T), rng.integers(10, N, T), rng.integers(0, 10, T)], 1).astype(np.int32)
     # relations would be hot rows (10 ids): give every triple its own pseudo-relation row instead
     tri[:, 2] = rng.integers(10, N, T)
@@ -842,12 +844,14 @@ def test_hole_resident_spectral_trainer_equals_per_call_transform(H):
 
 # ---------------------------------------------------------------- the prepare launch on its own
 @pytest.mark.parametrize("B,N_extra,direct,mode", [(4096, 0, True, 0), (1000, 0, True, 1), (37, 0, False, 2),
-                                                   (4096, 1_200_000, True, 0), (8192, 0, False, 0), (300, 70_000, True, 3)])
+                                                   (4096, 1_200_000, True, 0), (8192, 0, False, 0), (300, 70_000, True, 3),
+                                                   (8192, 0, True, 0), (13000, 1_200_000, True, 1), (16384, 0, True, 0)])
 def test_prepared_records_equal_numpy_model(H, B, N_extra, direct, mode):
-    """ge_train_prepare_steps (sampler + stable LDS radix sort by row + work-item cut) against a NumPy
+    """ge_train_prepare_steps (sampler + stable radix sort by row + work-item cut) against a NumPy
     model of the same record, word for word: negatives (C oracle), the slots tagged for direct update,
     every item's (row, count, multi) and slot list in (row, slot) order.  Covers 2 radix passes (FB15k
-    rows) and 3 (1.2 M rows), partial sub-batches, 2 sub-batches (B = 8192), unknown-type rows (-1)."""
+    rows) and 3 (1.2 M rows), partial tiles, the multi-workgroup sort (B = 8192: 2 tiles, 13000: 4 with a
+    partial one, 16384: 4; FB15k's hot relation rows give runs that cross tile boundaries), unknown-type rows (-1)."""
     from graphembeddings_amd import data as D
     import prep_model as PM
     fb = D.fb15k_shape()
@@ -883,7 +887,7 @@ def test_prepared_records_equal_numpy_model(H, B, N_extra, direct, mode):
 
 
 def test_train_steps_large_batch_and_fallback_branch(H):
-    """B = 8192 (two sort sub-batches per step, row updates combined atomically) and the fallback branch
+    """B = 8192 (the step's keys sorted across two workgroups) and the fallback branch
     of ge_train_steps (workspace without room for prepared records: per-step sampler + float-atomic
     scatter) both reproduce the C port's loop."""
     from graphembeddings_amd import data as D
@@ -913,6 +917,38 @@ def test_train_steps_large_batch_and_fallback_branch(H):
         assert np.abs(emb.cpu().numpy() - ctab).max() < 1e-4, prepared
         assert np.array_equal(tr._neg.cpu().numpy(), neg)
         tr.close()
+
+
+@pytest.mark.parametrize("B,n_ent", [(16384, 300_000), (65536, 1_200_000)])
+def test_train_steps_multi_tile_batches_vs_c_port(H, B, n_ent):
+    """The native loop above B = 4096 (BASELINE config 4's per-GPU batch: 65,536 pairs on the 1.2 M-row table, and
+    16,384 on a smaller one): the step's 4B keys are sorted across workgroups (ge_prep_big.hip), sole-slot rows are
+    updated by the producing pair and every other row by ONE read-modify-write.  Three dependent steps against
+    the C port replaying the same batches and Philox negatives."""
+    from graphembeddings_amd import data as D
+    data, tri = D.synthetic_large(n_entities=n_ent, n_triples=3 * B + 5, seed=77)
+    names, id_to_type, offsets, ids = D.synthetic_large_type_arrays(data)
+    N, d, steps = data.entity_count, 200, 3
+    rng = np.random.default_rng(3)
+    table = (rng.standard_normal((N, d)) * 0.05).astype(np.float32)
+    table[::4] *= 7.0
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    emb = dev(table).clone()
+    tr = H.Trainer(emb, dev(tri), tt, B, margin=0.2, learning_rate=0.1, decay_steps=40.0, decay_rate=0.5, seed=9)
+    losses = tr.run(steps, keep_losses=True).cpu().numpy()
+    ctab, row = table, 0
+    for s in range(steps):
+        if row + B > len(tri):
+            row = 0
+        pos = tri[row:row + B]
+        neg = CO.corrupt_batch(pos, id_to_type, offsets, ids, 9, s, 1024, 0)
+        lr = np.float32(0.1) / (np.float32(1.0) + np.float32(0.5) * (np.float32(s) / np.float32(40.0)))
+        closs = CO.hinge_step(ctab, pos, neg, 0.2, float(lr), threads=16)
+        assert np.abs(losses[s] - closs).max() < 2e-5, s
+        row += B
+    assert np.abs(emb.cpu().numpy() - ctab).max() < 1e-4
+    assert np.array_equal(tr._neg.cpu().numpy(), neg)
+    tr.close()
 
 
 def test_train_steps_lookahead_survives_between_calls(H):
