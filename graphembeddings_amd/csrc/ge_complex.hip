@@ -100,16 +100,17 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
 // h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
 // rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
-template <bool SPEC, int VEC, int LPT, int NITER>
+template <bool SPEC, bool SHARD, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
-    const int32_t* __restrict__ slot_item, float* table_rw) {
+    const int32_t* __restrict__ slot_item, float* table_rw, ShardGrad sg) {
   // slot_item + table_rw (training loop only, else null; table_rw aliases `rows`, which is therefore
   // NOT declared __restrict__ const in that instantiation): a slot tagged kSlotDirect is the ONLY
   // gradient slot of its table row in this step -- this pair is the row's only reader and writer -- so
   // the update is applied right here (rows + (-lr*g)) and no gradient row is written for it.
+  // SHARD: pos / neg are null; the pair's rows are named by sg.pos_src / sg.neg_src (see ShardGrad).
   constexpr int kSlotDirect = -2;
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
@@ -122,11 +123,25 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     const int64_t g = base + grp;
     const bool live = g < B;
     int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
-    if (live) {
+    bool bad;
+    if (SHARD) {
+      int32_t ns = -1;
+      if (live) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+        for (int c = 0; c < 3; ++c) p[c] = sg.pos_src[3 * g + c];
+        ns = sg.neg_src[g];
+      }
+      bad = p[0] < 0 || p[1] < 0 || p[2] < 0;
+      n[0] = (ns >= 0 && (ns & 1) == 0) ? (ns >> 1) : p[0];
+      n[1] = (ns >= 0 && (ns & 1) == 1) ? (ns >> 1) : p[1];
+      n[2] = p[2];
+    } else {
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+      }
+      bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
     }
-    const bool bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
     // the six "applied by the producer" tags of this pair, requested together with its ids (not after the forward)
     int32_t tag[6] = {0, 0, 0, 0, 0, 0};
@@ -134,11 +149,14 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
 #pragma unroll
       for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
     }
+    auto row_ptr = [&](int32_t id) -> const float* {
+      return (SHARD && id >= sg.R) ? sg.staged + (int64_t)(id - sg.R) * d : rows + (int64_t)id * d;
+    };
     Row<VEC, NITER> xp[3], xn[3];
 #pragma unroll
-    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, xp[X]);
+    for (int X = 0; X < 3; ++X) load_row_at<VEC, LPT, NITER>(row_ptr(p[X]), k, nvec, sub, xp[X]);
 #pragma unroll
-    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, n[X], d, k, nvec, sub, xn[X]);
+    for (int X = 0; X < 3; ++X) load_row_at<VEC, LPT, NITER>(row_ptr(n[X]), k, nvec, sub, xn[X]);
     const SideFwd fp = side_forward<SPEC, VEC, LPT, NITER>(xp[0], xp[1], xp[2], max_norm, sub == 0, wscale);
     const SideFwd fn = side_forward<SPEC, VEC, LPT, NITER>(xn[0], xn[1], xn[2], max_norm, sub == 0, wscale);
     const float pre = fp.sig - fn.sig + margin;
@@ -149,17 +167,35 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     for (int X = 0; X < 3; ++X) {
       const bool same = p[X] == n[X];
       const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
+      // local direct: row + gradient; remote direct (SHARD, tag <= -3): the gradient row itself into the send buffer
       const bool dirP = slot_item && live && tag[X] == kSlotDirect;
       const bool dirN = slot_item && live && !same && tag[3 + X] == kSlotDirect;
+      const bool sndP = SHARD && slot_item && live && tag[X] <= -3;
+      const bool sndN = SHARD && slot_item && live && !same && tag[3 + X] <= -3;
       if (live && sub == 0) {
-        grad_idx[rowP] = (on && !dirP) ? p[X] : -1;
-        grad_idx[rowN] = (on && !same && !dirN) ? n[X] : -1;
+        grad_idx[rowP] = (on && !dirP && !sndP) ? p[X] : -1;
+        grad_idx[rowN] = (on && !same && !dirN && !sndN) ? n[X] : -1;
       }
-      if (!on) continue;
+      if (!on) {
+        // a remote row's only gradient slot is inactive: the owner still receives a row for it -- zeros
+        if (SHARD && (sndP || sndN)) {
+          float z[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+#pragma unroll
+          for (int it = 0; it < NITER; ++it) {
+            const int j = sub + it * LPT;
+            if (j >= nvec) continue;
+            if (sndP) { float* o = sg.gsum + (int64_t)(-3 - tag[X]) * d; store_vec<VEC>(o + j * VEC, z); store_vec<VEC>(o + k + j * VEC, z); }
+            if (sndN) { float* o = sg.gsum + (int64_t)(-3 - tag[3 + X]) * d; store_vec<VEC>(o + j * VEC, z); store_vec<VEC>(o + k + j * VEC, z); }
+          }
+        }
+        continue;
+      }
       const RowCoef kp = row_coef(cp, fp, X, max_norm, neg_lr);
       const RowCoef kn = row_coef(cn, fn, X, max_norm, neg_lr);
-      float* gp = dirP ? table_rw + (int64_t)p[X] * d : grad_val + rowP * d;
-      float* gn = dirN ? table_rw + (int64_t)n[X] * d : grad_val + rowN * d;
+      float* gp = dirP ? table_rw + (int64_t)p[X] * d : sndP ? sg.gsum + (int64_t)(-3 - tag[X]) * d : grad_val + rowP * d;
+      float* gn = dirN ? table_rw + (int64_t)n[X] * d : sndN ? sg.gsum + (int64_t)(-3 - tag[3 + X]) * d : grad_val + rowN * d;
 #pragma unroll
       for (int it = 0; it < NITER; ++it) {
         const int j = sub + it * LPT;
@@ -388,7 +424,27 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw)
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, false, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw, ShardGrad{})
+  GE_DISPATCH_SPEC(spectral, s, CALL);
+#undef CALL
+  return launch_status();
+}
+
+// the row-sharded step's form: rows from the shard (in place) and from the staging buffer of fetched rows
+int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const int32_t* pos_src, const int32_t* neg_src,
+                            const int32_t* slot_item, int32_t R, int64_t B, float margin, float lr, float max_norm,
+                            float* loss, int32_t* grad_idx, float* grad_val, float* gsum, int spectral, hipStream_t st,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+  Shape s;
+  if (!pick_shape(d, shard, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
+  for (const void* q : {(const void*)grad_val, (const void*)staged, (const void*)gsum})
+    if (q && (reinterpret_cast<uintptr_t>(q) % (s.vec * 4)) != 0) return GE_EINVAL;
+  if (B == 0) return 0;
+  const int gpb = (kBlock / kWave) * (kWave / s.lpt);
+  const int grid = grid_for(B, gpb);
+  const ShardGrad sg{staged, R, pos_src, neg_src, gsum};
+#define CALL(V, L, NI) \
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, true, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg)
   GE_DISPATCH_SPEC(spectral, s, CALL);
 #undef CALL
   return launch_status();

@@ -23,9 +23,16 @@ struct Row {
 };
 
 template <int VEC, int LPT, int NITER>
+__device__ __forceinline__ void load_row_at(const float* __restrict__ p, int k, int nvec, int sub, Row<VEC, NITER>& R);
+
+template <int VEC, int LPT, int NITER>
 __device__ __forceinline__ void load_row(const float* __restrict__ rows, int32_t id, int d, int k,
                                          int nvec, int sub, Row<VEC, NITER>& R) {
-  const float* p = rows + (int64_t)id * d;
+  load_row_at<VEC, LPT, NITER>(rows + (int64_t)id * d, k, nvec, sub, R);
+}
+
+template <int VEC, int LPT, int NITER>
+__device__ __forceinline__ void load_row_at(const float* __restrict__ p, int k, int nvec, int sub, Row<VEC, NITER>& R) {
 #pragma unroll
   for (int it = 0; it < NITER; ++it) {
     const int j = sub + it * LPT;
@@ -97,6 +104,18 @@ __device__ __forceinline__ SideFwd side_forward(const Row<VEC, NITER>& h, const 
   o.sig = sigmoidf_dev(o.s);
   return o;
 }
+
+// The row-sharded step (ge_shard.hip, sharded.py): a pair's rows come from two stores -- ids below R are rows of
+// this rank's shard (read in place), R + u is row u of the staging buffer that holds the rows fetched from
+// the other owners -- and a gradient row with a tag <= -3 is the only one of its (remote) row in this step: it
+// is stored straight into row -3 - tag of the send buffer `gsum` instead of being queued for the reduction.
+struct ShardGrad {
+  const float* staged;
+  int32_t R;
+  const int32_t* pos_src;   // [B][3]
+  const int32_t* neg_src;   // [B]
+  float* gsum;
+};
 
 __device__ __forceinline__ bool bad3(int64_t N, int32_t a, int32_t b, int32_t c) {
   return a < 0 || b < 0 || c < 0 || a >= N || b >= N || c >= N;

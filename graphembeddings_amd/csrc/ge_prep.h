@@ -60,6 +60,35 @@ __host__ __device__ inline PrepLayout prep_layout(int64_t B, int64_t negs = 0) {
   return L;
 }
 
+// what the multi-tile kernels (ge_prep_big.hip) need to know about a record: the native loops derive it from a
+// PrepLayout, the row-sharded step's owner side (ge_shard.hip) from the longest request list of the chunk
+struct TileGeom {
+  int P, n_sub;                 // keys per tile, tiles per step
+  int64_t stride;               // int32 words per step record
+  int64_t off_slot;             // slot_item inside a record (-1: the record has none)
+  int64_t off_sub, sub_stride;  // tile 0, words per tile
+  int off_items, off_islots;
+};
+inline TileGeom geom_of(const PrepLayout& L) {
+  return TileGeom{(int)L.P, (int)L.n_sub, L.stride, L.off_slot, L.off_sub, L.sub_stride, (int)L.off_items, (int)L.off_islots};
+}
+// a record that is nothing but tiles { n_items, pad to 64 | items[P][2] | islots[P][16] }
+inline TileGeom geom_plain(int P, int n_sub) {
+  const int64_t sub = 64 + 2 * (int64_t)P + kItemCap * (int64_t)P;
+  return TileGeom{P, n_sub, n_sub * sub, -1, 0, sub, 64, 64 + 2 * P};
+}
+
+// row-sharded step (ge_shard.hip): what the items kernel adds per step when rows >= R are REMOTE rows (sorted by
+// owner, then row): their index u in the step's staging order, where every slot reads its row from, the request list
+struct ShardOut {
+  int32_t R;                    // rows < R: this rank's shard rows; R + u: staged row u of the step
+  int64_t B;
+  int32_t* pos_src;             // [S][3B]  per pair and column: shard row, or R + u; -1 = invalid pair
+  int32_t* neg_src;             // [S][B]   (source << 1 | column) of the corrupted entity, -1 = none of its own
+  int32_t* req_row;             // [S][n_sub * P]  row u's index in its owner's shard
+  const int32_t* tile_heads;    // [S][n_sub] distinct remote rows that START in each tile
+};
+
 // radix-sort geometry for row ids < N: n_pass passes of `bits` bits (>= 6: one counter per thread in the scan)
 struct SortBits { int n_pass, bits; };
 inline SortBits sort_bits_for(int64_t N) {

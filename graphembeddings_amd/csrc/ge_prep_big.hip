@@ -136,21 +136,26 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_scatter_kernel(
 }
 
 // ---------------------------------------------------------------- work items of one sorted tile
-// LDS: keys[P] | wtot[32] | rs_in.  Positions are GLOBAL (tile * P + i) so that runs continue across tiles.
+// LDS: keys[P] | wtot[32].  Positions are GLOBAL (tile * P + i) so that runs continue across tiles.
+// SHARD (the row-sharded step, ge_shard.hip): rows >= so.R are remote rows in staging order.  Their runs are
+// numbered u = 0, 1, .. across the step (remote heads in earlier tiles come from so.tile_heads); every key
+// tells its slot where the row is read from (so.pos_src / so.neg_src), a remote head adds its row to the
+// request list, a sole remote slot is tagged -3 - u (the producing pair stores its gradient row straight into
+// the send buffer) and items of remote rows carry R + u as their row.
+template <bool SHARD>
 __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
-    const unsigned long long* __restrict__ sorted, int64_t B, int negs, int direct, int32_t* __restrict__ prep) {
+    const unsigned long long* __restrict__ sorted, TileGeom G, int direct, int32_t* __restrict__ prep, ShardOut so) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-  const PrepLayout L = prep_layout(B, negs);
-  const int P = (int)L.P, R = P / kPrepThreads, seg = kWave * R, n_sub = (int)L.n_sub;
+  const int P = G.P, R = P / kPrepThreads, seg = kWave * R, n_sub = G.n_sub;
   int* wtot = reinterpret_cast<int*>(keys + P);
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, tile = blockIdx.y;
   const unsigned long long* g = sorted + (int64_t)blockIdx.x * n_sub * P;
   const int total = n_sub * P, base = tile * P;
-  int32_t* rec = prep + (int64_t)blockIdx.x * L.stride;
-  int32_t* slot_item = rec + L.off_slot;
-  int32_t* subrec = rec + L.off_sub + tile * L.sub_stride;
-  int32_t* items = subrec + L.off_items;
-  int32_t* islots = subrec + L.off_islots;
+  int32_t* rec = prep + (int64_t)blockIdx.x * G.stride;
+  int32_t* slot_item = G.off_slot >= 0 ? rec + G.off_slot : nullptr;
+  int32_t* subrec = rec + G.off_sub + tile * G.sub_stride;
+  int32_t* items = subrec + G.off_items;
+  int32_t* islots = subrec + G.off_islots;
   for (int i = tid; i < P; i += kPrepThreads) keys[i] = g[base + i];
   if (tid == 0) {
     // a run that began in an earlier tile: its first position, by binary search over the sorted sequence
@@ -165,9 +170,13 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
       }
     }
     wtot[31] = rs;
+    int before = 0;                                   // remote rows that start in earlier tiles
+    if (SHARD)
+      for (int t = 0; t < tile; ++t) before += so.tile_heads[(int64_t)blockIdx.x * n_sub + t];
+    wtot[30] = before;
   }
   __syncthreads();
-  const int rs_in = wtot[31];
+  const int rs_in = wtot[31], u_before = wtot[30];
   // i is tile-relative and may leave [0, P): the neighbours come from global memory
   auto key_at = [&](int i) -> unsigned long long {
     if (i >= 0 && i < P) return keys[i];
@@ -190,9 +199,9 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
   int prev_max = rs_in;
   for (int w = 0; w < wave; ++w) prev_max = max(prev_max, wtot[w]);
   __syncthreads();
-  // (b) item starts, counted
-  unsigned start_mask = 0;
-  int idx_loc[16], rs_loc[16];
+  // (b) item starts and remote heads, counted together: low 16 bits items, high 16 bits remote heads (<= P each)
+  unsigned start_mask = 0, sole_mask = 0, rhead_mask = 0;
+  int inc_loc[16], rs_loc[16];
   {
     int carry = 0, mcarry = prev_max;
 #pragma unroll
@@ -204,40 +213,64 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
         const uint32_t row = (uint32_t)(kk >> 32);
         const bool head = valid && (base + i == 0 || (uint32_t)(kp >> 32) != row);
         const bool sole = direct && head && !(kn != kInvalidKey && (uint32_t)(kn >> 32) == row);
+        const bool rhead = SHARD && head && row >= (uint32_t)so.R;
         const int rs = max(wave_incl_max(head ? base + i : -1, lane), mcarry);
         mcarry = __shfl(rs, kWave - 1, kWave);
         rs_loc[r] = rs;
         const bool start = valid && ((base + i - rs) % kItemCap) == 0 && !sole;
         if (start) start_mask |= 1u << r;
-        if (sole) slot_item[(uint32_t)kk] = kSlotDirect;
-        const int incl = wave_incl_add(start ? 1 : 0, lane) + carry;
-        idx_loc[r] = incl - (start ? 1 : 0);
+        if (sole) sole_mask |= 1u << r;
+        if (rhead) rhead_mask |= 1u << r;
+        const int incl = wave_incl_add((start ? 1 : 0) | (rhead ? 1 << 16 : 0), lane) + carry;
+        inc_loc[r] = incl;
         carry = __shfl(incl, kWave - 1, kWave);
       }
     }
     if (lane == 0) wtot[wave] = carry;
   }
   __syncthreads();
-  int prev_items = 0, n_items = 0;
-  for (int w = 0; w < kPrepWaves; ++w) { if (w < wave) prev_items += wtot[w]; n_items += wtot[w]; }
-  if (tid == 0) subrec[0] = n_items;
+  int prev = 0, all = 0;
+  for (int w = 0; w < kPrepWaves; ++w) { if (w < wave) prev += wtot[w]; all += wtot[w]; }
+  if (tid == 0) subrec[0] = all & 0xFFFF;
+  const int prev_items = prev & 0xFFFF, u0 = u_before + (prev >> 16) - 1;   // u = u0 + remote heads at or before
   // (c) emit
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    if (r < R && ((start_mask >> r) & 1u)) {
+    if (r < R) {
       const int i = wave * seg + r * kWave + lane;
-      const uint32_t row = (uint32_t)(keys[i] >> 32);
-      const int idx = prev_items + idx_loc[r];
-      int e = i + 1;
-      unsigned long long ke = key_at(e);
-      while ((e - i) < kItemCap && ke != kInvalidKey && (uint32_t)(ke >> 32) == row) { ++e; ke = key_at(e); }
-      const bool more = ke != kInvalidKey && (uint32_t)(ke >> 32) == row;
-      const bool multi = (base + i != rs_loc[r]) || more;
-      items[2 * idx] = (int32_t)row;
-      items[2 * idx + 1] = (e - i) | (multi ? (1 << 30) : 0);
+      const unsigned long long kk = keys[i];
+      const bool valid = kk != kInvalidKey;
+      uint32_t row = (uint32_t)(kk >> 32);
+      const uint32_t slot = (uint32_t)kk;
+      const bool sole = (sole_mask >> r) & 1u;
+      int tag = kSlotDirect;
+      if (SHARD && valid) {
+        const bool remote = row >= (uint32_t)so.R;
+        const int u = u0 + (inc_loc[r] >> 16);
+        if (remote) {
+          if ((rhead_mask >> r) & 1u) so.req_row[(int64_t)blockIdx.x * total + u] = (int32_t)(row % (uint32_t)so.R);
+          row = (uint32_t)so.R + (uint32_t)u;
+          tag = -3 - u;
+        }
+        const uint32_t pair = slot / 6u, X = slot - pair * 6u;
+        if (X < 3) so.pos_src[((int64_t)blockIdx.x * so.B + pair) * 3 + X] = (int32_t)row;
+        else so.neg_src[(int64_t)blockIdx.x * so.B + pair] = (int32_t)((row << 1) | (X - 3u));
+      }
+      if (sole) slot_item[slot] = tag;
+      if ((start_mask >> r) & 1u) {
+        const uint32_t krow = (uint32_t)(kk >> 32);
+        const int idx = prev_items + (inc_loc[r] & 0xFFFF) - 1;
+        int e = i + 1;
+        unsigned long long ke = key_at(e);
+        while ((e - i) < kItemCap && ke != kInvalidKey && (uint32_t)(ke >> 32) == krow) { ++e; ke = key_at(e); }
+        const bool more = ke != kInvalidKey && (uint32_t)(ke >> 32) == krow;
+        const bool multi = (base + i != rs_loc[r]) || more;
+        items[2 * idx] = (int32_t)row;
+        items[2 * idx + 1] = (e - i) | (multi ? (1 << 30) : 0);
 #pragma unroll
-      for (int j = 0; j < kItemCap; ++j)
-        islots[idx * kItemCap + j] = (i + j < e) ? (int32_t)(uint32_t)key_at(i + j) : -1;
+        for (int j = 0; j < kItemCap; ++j)
+          islots[idx * kItemCap + j] = (i + j < e) ? (int32_t)(uint32_t)key_at(i + j) : -1;
+      }
     }
   }
 }
@@ -245,13 +278,53 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
 // ---------------------------------------------------------------- host
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// scratch of one prepare sequence over n steps: two key arrays (ping-pong) + the digit counts of one pass
+// scratch of one sort over n steps of n_sub tiles of P keys: two key arrays (ping-pong) + the digit counts of one pass
+size_t sort_scratch_bytes(int64_t n, int64_t n_sub, int64_t P) {
+  const size_t keys = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)n_sub * (size_t)P, 256);
+  const size_t hist = align_up_sz(sizeof(unsigned) * (size_t)n * kMaxRadix * (size_t)n_sub, 256);
+  return 2 * keys + hist;
+}
+unsigned long long* sort_scratch_keys(void* scratch) { return reinterpret_cast<unsigned long long*>(scratch); }
+
+// stable LSD radix sort of the keys in scratch (as written by a key kernel) on their row field (< n_rows);
+// returns the array that holds the result
+const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st) {
+  const SortBits sb = sort_bits_for(n_rows);
+  const size_t keys_bytes = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)n_sub * (size_t)P, 256);
+  unsigned long long* ka = reinterpret_cast<unsigned long long*>(scratch);
+  unsigned long long* kb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + keys_bytes);
+  unsigned* hist = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + 2 * keys_bytes);
+  const dim3 grid((unsigned)n, (unsigned)n_sub), block(kPrepThreads);
+  for (int pass = 0; pass < sb.n_pass; ++pass) {
+    const int shift = 32 + pass * sb.bits;
+    hipLaunchKernelGGL(prep_big_hist_kernel, grid, block, 0, st, ka, (int)P, (int)n_sub, shift, sb.bits, hist);
+    hipLaunchKernelGGL(prep_big_scatter_kernel, grid, block, 0, st, ka, kb, hist, (int)P, (int)n_sub, shift, sb.bits);
+    unsigned long long* t = ka; ka = kb; kb = t;
+  }
+  return ka;
+}
+
+int items_launch(const unsigned long long* sorted, int64_t n, const TileGeom& G, int direct, int32_t* out, const ShardOut* so,
+                 hipStream_t st) {
+  const size_t lds = sizeof(unsigned long long) * (size_t)G.P + sizeof(int) * 32;
+  const dim3 grid((unsigned)n, (unsigned)G.n_sub), block(kPrepThreads);
+  if (so) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prep_big_items_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(prep_big_items_kernel<true>, grid, block, lds, st, sorted, G, direct, out, *so);
+  } else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prep_big_items_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(prep_big_items_kernel<false>, grid, block, lds, st, sorted, G, direct, out, ShardOut{});
+  }
+  return launch_status();
+}
+
 size_t prep_big_scratch_bytes(int64_t B, int64_t negs, int64_t n) {
   const PrepLayout L = prep_layout(B, negs);
-  if (L.n_sub <= 1) return 0;
-  const size_t keys = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)L.n_sub * (size_t)L.P, 256);
-  const size_t hist = align_up_sz(sizeof(unsigned) * (size_t)n * kMaxRadix * (size_t)L.n_sub, 256);
-  return 2 * keys + hist;
+  return L.n_sub <= 1 ? 0 : sort_scratch_bytes(n, L.n_sub, L.P);
 }
 
 int prepare_big_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n,
@@ -259,26 +332,11 @@ int prepare_big_launch(const int32_t* triples, int64_t T, int64_t first_row, int
                        const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
                        int32_t mode, int direct, int32_t* out, void* scratch, hipStream_t st, int negs) {
   const PrepLayout L = prep_layout(B, negs);
-  const SortBits sb = sort_bits_for(N);
-  const size_t keys_bytes = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)L.n_sub * (size_t)L.P, 256);
-  unsigned long long* ka = reinterpret_cast<unsigned long long*>(scratch);
-  unsigned long long* kb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + keys_bytes);
-  unsigned* hist = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + 2 * keys_bytes);
   const dim3 grid((unsigned)n, (unsigned)L.n_sub), block(kPrepThreads);
   hipLaunchKernelGGL(prep_big_keys_kernel, grid, block, 0, st, triples, T, first_row, B, s0, id_to_type, N, type_offsets,
-                     n_types, type_ids, seed, global_step0, padded_size, mode, direct, negs, out, ka);
-  for (int pass = 0; pass < sb.n_pass; ++pass) {
-    const int shift = 32 + pass * sb.bits;
-    hipLaunchKernelGGL(prep_big_hist_kernel, grid, block, 0, st, ka, (int)L.P, (int)L.n_sub, shift, sb.bits, hist);
-    hipLaunchKernelGGL(prep_big_scatter_kernel, grid, block, 0, st, ka, kb, hist, (int)L.P, (int)L.n_sub, shift, sb.bits);
-    unsigned long long* t = ka; ka = kb; kb = t;
-  }
-  const size_t lds = sizeof(unsigned long long) * (size_t)L.P + sizeof(int) * 32;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prep_big_items_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(prep_big_items_kernel, grid, block, lds, st, ka, B, negs, direct, out);
-  return launch_status();
+                     n_types, type_ids, seed, global_step0, padded_size, mode, direct, negs, out, sort_scratch_keys(scratch));
+  const unsigned long long* sorted = sort_tiles_launch(scratch, n, L.n_sub, L.P, N, st);
+  return items_launch(sorted, n, geom_of(L), direct, out, nullptr, st);
 }
 
 }  // namespace ge

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
 template <int NJ>
 __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
-    int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val) {
+    int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val, int split,
+    float* __restrict__ out2) {
+  // grad_idx == null: every listed slot is live (the owner side of the row-sharded step sums received rows).
+  // Rows >= split (row-sharded step only) are rows of ANOTHER owner: their sum is stored to row - split of the
+  // send buffer out2 (zeroed beforehand: split rows add atomically) instead of being added to the table.
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
@@ -239,18 +243,19 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     int slot_v = (lane < kItemCap) ? islots[w * kItemCap + lane] : -1;
     const int cnt = cm & 0x3FFFFFFF;
     const bool multi = (cm >> 30) & 1;
-    float* dst = table + (int64_t)row * d;
+    const bool away = row >= split;
+    float* dst = away ? out2 + (int64_t)(row - split) * d : table + (int64_t)row * d;
     // the table row is fetched now, under the gradient-row loads, not after them
     float base[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + kWave * j;
-      base[j] = (!multi && c < d) ? dst[c] : 0.f;
+      base[j] = (!multi && !away && c < d) ? dst[c] : 0.f;
     }
-    const bool act_v = slot_v >= 0 && grad_idx[slot_v] >= 0;   // pair was hinge-active
+    const bool act_v = slot_v >= 0 && (!grad_idx || grad_idx[slot_v] >= 0);   // pair was hinge-active
     if (slot_v < 0) slot_v = 0;
     const unsigned long long live = __ballot(act_v);
-    if (live == 0ull) continue;  // wave-uniform
+    if (live == 0ull && !(away && !multi)) continue;  // wave-uniform (a remote row is sent whatever it sums to)
     float acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
@@ -289,17 +294,21 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
   }
 }
 
-static int apply_sorted_launch(float* table, int d, const PrepLayout& L, const int32_t* step_rec,
-                               const int32_t* gidx, const float* gval, hipStream_t st, hipEvent_t ev_start,
-                               hipEvent_t ev_stop) {
-  const int grid = grid_for(L.P, kBlock / kWave);  // at most P items per sub-batch
+int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* step_rec, const int32_t* gidx,
+                       const float* gval, int split, float* out2, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  const int grid = grid_for(G.P, kBlock / kWave);  // at most P items per tile
   const int nj = (d + kWave - 1) / kWave;
-  const dim3 g((unsigned)grid, (unsigned)L.n_sub);
-#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + L.off_sub, L.sub_stride, (int)L.off_items, (int)L.off_islots, gidx, gval)
+  const dim3 g((unsigned)grid, (unsigned)G.n_sub);
+#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2)
   if (nj <= 1) LA(1); else if (nj <= 2) LA(2); else if (nj <= 4) LA(4); else if (nj <= 8) LA(8); else if (nj <= 16) LA(16);
   else return GE_ENOTSUP;
 #undef LA
   return launch_status();
+}
+
+static int apply_sorted_launch(float* table, int d, const PrepLayout& L, const int32_t* step_rec, const int32_t* gidx,
+                               const float* gval, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  return apply_items_launch(table, d, geom_of(L), step_rec, gidx, gval, 0x7FFFFFFF, nullptr, st, ev_start, ev_stop);
 }
 
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -510,6 +510,72 @@ def plan_items(first_pos, n_runs, cap, it_incl, sp_incl, row_of, bucket, step_st
     return begin, length, target, split_rows
 
 
+# ---------------------------------------------------------------- the row-sharded step (csrc/ge_shard.hip)
+def shard_plan(pos: torch.Tensor, neg: torch.Tensor, n_rows: int, world: int, rank: int):
+    """ge_shard_plan for S steps: pos, neg [S,B,3] int32 global ids -> (records [S,W], pos_src [S,B,3], neg_src [S,B],
+    req_row [S,cap], counts [S,world]) -- see include/ge_hip.h."""
+    _i32(pos, "pos"), _i32(neg, "neg")
+    S, B = int(pos.shape[0]), int(pos.shape[1])
+    lay = prepared_layout(B)
+    dev = pos.device
+    records = torch.empty(S, lay[0], dtype=torch.int32, device=dev)
+    pos_src = torch.empty(S, B, 3, dtype=torch.int32, device=dev)
+    neg_src = torch.empty(S, B, dtype=torch.int32, device=dev)
+    req_row = torch.empty(S, 4 * lay[1] * lay[2], dtype=torch.int32, device=dev)
+    counts = torch.empty(S, world, dtype=torch.int32, device=dev)
+    need = int(_lib.load().ge_shard_plan_workspace_bytes(B, S))
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    _lib.call("ge_shard_plan", pos.data_ptr(), neg.data_ptr(), S, B, int(n_rows), int(world), int(rank), records.data_ptr(),
+              pos_src.data_ptr(), neg_src.data_ptr(), req_row.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return records, pos_src, neg_src, req_row, counts
+
+
+def shard_grad(shard: torch.Tensor, staged, pos_src, neg_src, record, B: int, n_rows: int, world: int, lr: float,
+               margin: float, model, max_norm: float, grad_idx: torch.Tensor, grad_val: torch.Tensor, gsum) -> torch.Tensor:
+    """ge_shard_grad: one step's fused gather/score/hinge/grad on the shard (in place) + the staged rows; returns loss [B]."""
+    shard = _table(shard)
+    n_staged = 0 if staged is None else int(staged.shape[0])
+    loss = torch.empty(B, dtype=torch.float32, device=shard.device)
+    _lib.call("ge_shard_grad", shard.data_ptr(), shard.shape[0], shard.shape[1], staged.data_ptr() if n_staged else None,
+              n_staged, pos_src.data_ptr(), neg_src.data_ptr(), record.data_ptr(), int(B), int(n_rows), int(world),
+              float(margin), float(lr), float(max_norm), _MODELS[model], loss.data_ptr(), grad_idx.data_ptr(),
+              grad_val.data_ptr(), gsum.data_ptr() if n_staged else None, _stream())
+    return loss
+
+
+def shard_apply(shard: torch.Tensor, record, B: int, n_rows: int, world: int, grad_idx, grad_val, gsum) -> None:
+    """ge_shard_apply: own rows updated in place, staged rows' gradient sums into gsum."""
+    shard = _table(shard)
+    _lib.call("ge_shard_apply", shard.data_ptr(), shard.shape[0], shard.shape[1], record.data_ptr(), int(B), int(n_rows),
+              int(world), grad_idx.data_ptr(), grad_val.data_ptr(), gsum.data_ptr() if gsum is not None and gsum.numel() else None,
+              _stream())
+
+
+def shard_owner_plan(req_all: torch.Tensor, req_start, rows_local: int):
+    """ge_shard_owner_plan: (records [S,W], cap) for the chunk's received request lists; req_start: host list [S+1]."""
+    S = len(req_start) - 1
+    cap = max([req_start[i + 1] - req_start[i] for i in range(S)] + [0])
+    dev = req_all.device
+    lib = _lib.load()
+    words = int(lib.ge_shard_owner_record_words(cap))
+    records = torch.empty(S, max(words, 1), dtype=torch.int32, device=dev)
+    if cap:
+        rs = torch.tensor(req_start, dtype=torch.int64).to(dev, non_blocking=False)
+        ws = torch.empty(max(int(lib.ge_shard_owner_workspace_bytes(cap, S)), 256), dtype=torch.uint8, device=dev)
+        _lib.call("ge_shard_owner_plan", _i32(req_all, "req_all").data_ptr(), rs.data_ptr(), S, cap, int(rows_local),
+                  records.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return records, cap
+
+
+def shard_owner_apply(shard: torch.Tensor, oplan, s: int, recv: torch.Tensor) -> None:
+    records, cap = oplan
+    if cap == 0 or recv.shape[0] == 0:
+        return
+    shard = _table(shard)
+    _lib.call("ge_shard_owner_apply", shard.data_ptr(), shard.shape[0], shard.shape[1], records[s].data_ptr(), int(cap),
+              recv.data_ptr(), _stream())
+
+
 class Trainer:
     """The inner loop of run_training (holE.py:340-362, minus validation) enqueued natively by
     ge_train_steps: per step a batch of the device-resident shuffled triple array, type-safe

@@ -349,6 +349,47 @@ int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row,
                            const int32_t* type_ids, uint64_t seed, uint64_t global_step0, int32_t padded_size,
                            int32_t mode, int direct, int32_t* out, size_t out_bytes, void* stream);
 
+/* --- the row-sharded training step (holE.py:287-296 on a table mod-sharded over G processes: owner = id % G,
+ * local row = id / G, R = ceil(N / G); the reference itself is single-device).  The host
+ * (graphembeddings_amd/sharded.py) moves rows and gradient sums with torch.distributed all-to-alls; these entry
+ * points are everything else.  All buffers device, caller-owned; nothing synchronises.
+ *
+ * ge_shard_plan -- requester side, for S steps of B pairs at once (pos, neg [S,B,3] GLOBAL ids; neg differs from
+ *   pos in at most one of head / tail, as ge_corrupt_batch produces; other pairs count as invalid):
+ *   records [S, ge_train_prepared_layout(B)[0]]: the step's work items in the native loop's record format, over
+ *     this rank's rows (read and updated in place) and, behind them, the other owners' rows in staging order
+ *     (an item row R + u = row u of the gradient-sum buffer); slot_item tags: -2 sole slot of an own row, -3 - u
+ *     sole slot of staged row u (the producing pair stores the row straight into the gradient-sum buffer);
+ *   pos_src [S,B,3], neg_src [S,B]: where each pair reads its rows (own row, or R + u; neg_src = source << 1 |
+ *     column of the corrupted entity, -1 when it has no row of its own; pos_src -1 = invalid pair);
+ *   req_row [S,4*Bt] (Bt = B rounded up to the record's tile size: layout[1] * layout[2]): entry u = staged row u's
+ *     index in its owner's shard, grouped by owner; counts [S,G]: rows requested from each owner. */
+size_t ge_shard_plan_workspace_bytes(int64_t B, int64_t S);
+int ge_shard_plan(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t G, int32_t rank,
+                  int32_t* records, int32_t* pos_src, int32_t* neg_src, int32_t* req_row, int32_t* counts,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* One step's fused gather -> clip -> score -> sigmoid -> hinge -> gradient rows on two row stores: the shard
+ * (rows < R, in place; sole-slot rows are updated here) and `staged` [n_staged,d], the rows fetched from the
+ * other owners.  gsum [n_staged,d] receives the gradient rows tagged -3 - u.  model: GE_MODEL_COMPLEX or
+ * GE_MODEL_HOLE_SPECTRAL.  loss [B], grad_idx [6B], grad_val [6B,d] as for ge_hinge_grad. */
+int ge_shard_grad(float* shard, int64_t rows_local, int32_t d, const float* staged, int64_t n_staged, const int32_t* pos_src,
+                  const int32_t* neg_src, const int32_t* record, int64_t B, int64_t N, int32_t G, float margin, float lr,
+                  float max_norm, int model, float* loss, int32_t* grad_idx, float* grad_val, float* gsum, void* stream);
+/* The step's work items: own rows get ONE read-modify-write each, staged rows their sum in gsum (which must be
+ * zero beforehand: rows with more than 16 slots combine atomically). */
+int ge_shard_apply(float* shard, int64_t rows_local, int32_t d, const int32_t* record, int64_t B, int64_t N, int32_t G,
+                   const int32_t* grad_idx, const float* grad_val, float* gsum, void* stream);
+/* Owner side: req_all = the chunk's received request lists (rows of this shard) in (step, peer) order, step s =
+ * [req_start[s], req_start[s+1]) (req_start: DEVICE int64 [S+1]); cap >= the longest per-step list.  records
+ * [S, ge_shard_owner_record_words(cap)]: work items that add row j of the step's receive buffer to shard row
+ * req[j] -- one read-modify-write per distinct row, fixed order. */
+int64_t ge_shard_owner_record_words(int64_t cap);
+size_t ge_shard_owner_workspace_bytes(int64_t cap, int64_t S);
+int ge_shard_owner_plan(const int32_t* req_all, const int64_t* req_start, int64_t S, int64_t cap, int64_t rows_local,
+                        int32_t* records, void* workspace, size_t workspace_bytes, void* stream);
+int ge_shard_owner_apply(float* shard, int64_t rows_local, int32_t d, const int32_t* record, int64_t cap, const float* recv,
+                         void* stream);
+
 /* --- thin wrappers over hipEvent_t so a ctypes host can time kernels on the launch stream. */
 int ge_event_create(void** ev);
 int ge_event_destroy(void* ev);

@@ -444,8 +444,9 @@ def test_sharded_trainer_single_rank_uses_hip_kernels(H, shape):
 
 @pytest.mark.parametrize("model", ["hole", "hole_spectral"])
 def test_sharded_trainer_hole_models_equal_the_plain_step(H, model):
-    """The row-sharded step with the HolE score (real table: direct correlation; spectral table: the ComplEx-shaped
-    form) at world size 1 equals the plain fused step of the same model on the same negatives."""
+    """The row-sharded step with the HolE score at world size 1: model="hole" (a real table; the trainer carries its
+    shard in the frequency domain and gather_full_table() hands real rows back) and "hole_spectral" (a table that
+    already is spectral) equal the plain fused step of the same model on the same negatives."""
     from graphembeddings_amd import data as D
     from graphembeddings_amd import sharded as S
     fb = D.fb15k_shape()
@@ -456,9 +457,9 @@ def test_sharded_trainer_hole_models_equal_the_plain_step(H, model):
     if model == "hole_spectral":
         H.hole_to_spectral(table)
     pos = dev(D.synthetic_fb15k_triples(fb, n_triples=B, seed=8))
-    a = table.clone()
-    tr = S.ShardedTrainer(a, fb.entity_count, tt, seed=4, model=model)
+    tr = S.ShardedTrainer(table.clone(), fb.entity_count, tt, seed=4, model=model)
     loss_s = tr.step(pos, lr=0.1)
+    a = tr.gather_full_table()
     neg = H.corrupt_batch(tt, fb.relation_count, pos, seed=4, step=0)
     b = table.clone()
     loss_p = H.HingeSGD(b, B, model=model).step(pos, neg, 0.1)[:, 0]
@@ -485,53 +486,51 @@ def test_rank_sweep_model_argument(H):
         H.rank_candidates(emb, hr, tid, cand, model="hole")
 
 
-def _plans_equal(p, q):
-    assert (p.S, p.B, p.sc, p.rc, p.req_start, p.unique_rows, p.remote_rows) == (q.S, q.B, q.sc, q.rc, q.req_start, q.unique_rows, q.remote_rows)
-    assert torch.equal(p.remap, q.remap) and torch.equal(p.req_all, q.req_all)
-    for a, b in ((p.reduce_items, q.reduce_items), (p.apply_items, q.apply_items)):
-        assert a.item_start == b.item_start and a.split_start == b.split_start
-        for f in ("order", "begin", "length", "target", "split_rows"):
-            x, y = getattr(a, f), getattr(b, f)
-            assert x.dtype == y.dtype and torch.equal(x, y), f
-
-
-@pytest.mark.parametrize("shape", ["fb15k", "config4", "hot"])
-def test_native_exchange_planner_equals_tensor_op_planner(H, shape):
-    """ge_plan_* (csrc/ge_plan.hip) vs the tensor-op planner of sharded.py on the same chunk: every field of the plan
-    word for word -- staging order, slot remap, request lists, and the work items of both reductions (incl. rows
-    split over several items: 'hot' puts 5000 slots on one row), with ids outside the table."""
+@pytest.mark.parametrize("shape,world,rank", [("fb15k", 1, 0), ("fb15k", 2, 1), ("hot", 3, 0), ("config4", 8, 5), ("config4", 1, 0)])
+def test_shard_plan_equals_numpy_model(H, shape, world, rank):
+    """ge_shard_plan (csrc/ge_shard.hip: virtual-row keys, multi-workgroup sort, work items, staging order) against the
+    NumPy model of the same plan, word for word, for every step of a chunk: the record's items and slot lists (own
+    rows, then staged rows R + u), the direct tags (-2 own, -3 - u staged), where every pair reads its rows, the
+    request list and the per-owner counts; with invalid ids, a pair whose negative equals its positive, rows split
+    over several items ('hot': 5000 slots on one row) and runs that cross tile boundaries (config4: B = 16,384)."""
     from graphembeddings_amd import data as D
-    from graphembeddings_amd import sharded as S
+    import prep_model as PM
     if shape == "config4":
-        S_, B = 3, 16384
+        S_, B = 2, 16384
         data, pos_h = D.synthetic_large(n_entities=1_200_000, n_triples=S_ * B, seed=77)
         names, id_to_type, offsets, ids = D.synthetic_large_type_arrays(data)
-        n_rows = data.entity_count
+        n_rows, n_rel = data.entity_count, data.relation_count
     else:
-        S_, B = 4, 2048
+        S_, B = 3, 2048 if shape == "fb15k" else 6000
         fb = D.fb15k_shape()
         names, id_to_type, offsets, ids = fb.type_arrays()
         pos_h = D.synthetic_fb15k_triples(fb, n_triples=S_ * B, seed=5)
-        n_rows = fb.entity_count
+        n_rows, n_rel = fb.entity_count, fb.relation_count
         if shape == "hot":
             pos_h[:5000, 0] = fb.relation_count + 17
     tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
-    shard = torch.zeros(n_rows, 8, device="cuda")
-    tr = S.ShardedTrainer(shard, n_rows, tt, seed=4)
-    pos = dev(pos_h).view(S_, B, 3)
-    neg = tr.sample_negatives(pos).to(torch.int32)
-    pos = pos.clone()
-    pos[1, 5, 0] = -3                                   # invalid ids: their slots stay empty
-    pos[2, 9, 1] = n_rows + 11
-    assert tr.k.native_planner
-    native = tr.plan_chunk(pos, neg)
-    tr.k.native_planner = False
-    try:
-        ref = tr.plan_chunk(pos, neg)
-    finally:
-        tr.k.native_planner = True
-    _plans_equal(native, ref)
-    assert shape != "hot" or len(native.reduce_items.split_rows) > 0
+    pos = dev(pos_h).view(S_, B, 3).clone()
+    neg = torch.stack([H.corrupt_batch(tt, n_rel, pos[s], seed=4, step=s) for s in range(S_)], 0)
+    pos[1, 5, 0] = -3                                   # invalid ids: the pair has no slots
+    pos[0, 9, 1] = n_rows + 11
+    neg[0, 3] = pos[0, 3]                               # negative == positive: no row of its own
+    records, pos_src, neg_src, req_row, counts = H.shard_plan(pos, neg, n_rows, world, rank)
+    torch.cuda.synchronize()
+    lay = H.prepared_layout(B)
+    for s in range(S_):
+        exp = PM.expected_shard_plan(pos[s].cpu().numpy(), neg[s].cpu().numpy(), n_rows, world, rank, lay)
+        got = PM.parse_record(records[s].cpu().numpy(), B, lay)
+        assert np.array_equal(counts[s].cpu().numpy(), exp["counts"]), s
+        U = len(exp["req_row"])
+        assert np.array_equal(req_row[s, :U].cpu().numpy(), exp["req_row"]), s
+        assert np.array_equal(pos_src[s].cpu().numpy(), exp["pos_src"]), s
+        assert np.array_equal(neg_src[s].cpu().numpy(), exp["neg_src"]), s
+        assert np.array_equal(got["slot_item"], exp["slot_item"]), s
+        assert got["n_items"] == exp["n_items"], (s, got["n_items"], exp["n_items"])
+        for t in range(lay[1]):
+            assert np.array_equal(got["items"][t], exp["items"][t]), (s, t)
+            assert np.array_equal(got["islots"][t], exp["islots"][t]), (s, t)
+    assert shape != "hot" or (got["items"][0][:, 1] >> 30).any()
 
 
 def test_validation_tick_matches_oracle_and_keeps_the_best_table(H):
