@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--sharded", action="store_true", help="run the row-sharded (all-to-all) path even on 1 GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-score-roofline", action="store_true")
+    ap.add_argument("--no-hbm-roofline", action="store_true",
+                    help="skip the HBM-bound leg of the train step (960 MB table, 65,536 pairs per step)")
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="skip the 1-GPU run of the row-sharded config[3] workload that the N>1 lines are comparable to")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -109,6 +111,51 @@ def score_kernel_roofline(d, n_rows=1_200_018, n_triples=1 << 22, iters=10):
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "kernel_ms": ms, "triples_per_launch": n_triples,
             "table_rows": n_rows, "table_mb": round(n_rows * d * 4 / 1e6, 1),
             "scored_triples_per_s": n_triples / (ms * 1e-3), "algorithmic_bytes_per_launch": alg}
+
+
+def train_step_hbm_roofline(d, B=SHARDED_BATCH, n_entities=1_200_000, steps=48):
+    """The whole train step where it is HBM-bound (the headline FB15k step is one round of waves on a 13 MB
+    cache-resident table and cannot show bandwidth): ge_train_steps on the 1.2 M-row table (960 MB > the 256 MB
+    Infinity Cache), Zipf(0.8) ids, B = 65,536 pairs per step.  Above B = 4096 the step's gradient slots are sorted
+    across workgroups (csrc/ge_prep_big.hip), so every distinct row still gets ONE plain read-modify-write.
+    Algorithmic bytes: 72d+28 per pair for the step, 24d+28 / 48d for its two kernels."""
+    import torch
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import hole as H
+    data, tri = D.synthetic_large(n_entities=n_entities, n_triples=max(8 * B, 2_000_000), seed=1234)
+    names, id_to_type, offsets, ids = D.synthetic_large_type_arrays(data)
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    dtri = torch.as_tensor(tri).cuda()
+    emb = H.init_embeddings(data.entity_count, d, seed=0)
+    tr = H.Trainer(emb, dtri, tt, B, margin=0.2, learning_rate=0.1, decay_steps=32.0 * (30_000_000 // B), seed=0)
+    tr.run(steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.run(steps)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    kern = {}
+    for k, name in ((1, "complex_hinge_grad_kernel"), (2, "apply_sorted_kernel")):
+        ev = H.Events(2 * steps)
+        tr.run(steps, events=ev.handles, ev_kernel=k)
+        torch.cuda.synchronize()
+        kern[name] = float(np.median([ev.elapsed_ms(2 * i, 2 * i + 1) for i in range(steps)]))
+        ev.close()
+    loss = float(tr.last_loss.mean())
+    tr.close()
+    del emb, tr, dtri
+    alg = {"step": (72 * d + 28) * B, "complex_hinge_grad_kernel": (24 * d + 28) * B, "apply_sorted_kernel": 48 * d * B}
+    traffic = {k: pmc_traffic(k, f"synthetic_d{d}_b{B}") for k in kern}
+    return {"workload": f"synthetic {n_entities} entities, complex d={d}, batch={B}, native loop (ge_train_steps), 1 GPU",
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "table_mb": round(data.entity_count * d * 4 / 1e6, 1),
+            "ms_per_step": el * 1e3, "scored_triples_per_s": 2.0 * B / el,
+            "achieved": alg["step"] / el / 1e9, "frac": alg["step"] / el / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_step": alg["step"],
+            "kernels": {k: {"kernel_ms": v, "algorithmic_bytes_per_launch": alg[k], "achieved": alg[k] / (v * 1e-3) / 1e9,
+                            "frac": alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": traffic[k]["hbm_bytes_per_launch"] if traffic[k] else None,
+                            "traffic_source": traffic[k]["source"] if traffic[k] else None} for k, v in kern.items()},
+            "final_mean_hinge": round(loss, 6)}
 
 
 def cpu_baseline_fb15k(fb, type_arrays, d, B, seconds):
@@ -286,6 +333,11 @@ def run_single(args):
         del scratch
     if not args.no_score_roofline:
         out["score_kernel_roofline"] = score_kernel_roofline(d)
+    if not args.no_hbm_roofline and args.workload == "auto" and args.model == "complex":
+        try:
+            out["train_step_hbm_roofline"] = train_step_hbm_roofline(d)
+        except Exception as e:  # never lose the headline line to an auxiliary leg
+            out["train_step_hbm_roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline and workload == "fb15k":
         out["cpu_baseline"] = cpu_baseline_fb15k(fb, arrays, d, B, args.cpu_seconds)
     elif not args.no_cpu_baseline:

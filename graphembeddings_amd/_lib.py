@@ -34,17 +34,10 @@ SYMBOLS = {
     "ge_complex_logloss_step": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),
     "ge_hinge_grad": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _f, _f, _f, C.c_int, _p, _p, _p, _p]),
     "ge_scatter_add_rows": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p]),
-    "ge_segment_sum_rows": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64, _i32, _p]),
     "ge_gather_rows": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p]),
     "ge_corrupt_batch": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _u64, _u64, _i32, _i32, _p, _p]),
     "ge_bernoulli_corrupt_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _i64, _p, _i32, _i32, _i32, _u64, _u64, _p, _p]),
     "ge_complex_score_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i64, _f, C.c_int, C.c_int, _p, _p]),
-    "ge_plan_keys": (C.c_int, [_p, _p, _i64, _i64, _i64, _i64, _p, C.c_int, _p]),
-    "ge_plan_flags": (C.c_int, [_p, _i64, C.c_int, _p, _p]),
-    "ge_plan_heads": (C.c_int, [_p, _p, _i64, C.c_int, _i64, _p, _p, _p, _p]),
-    "ge_plan_scatter": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
-    "ge_plan_item_counts": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
-    "ge_plan_items": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "ge_validation_workspace_bytes": (C.c_size_t, [_i64]),
     "ge_validation_tick": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _i32, _p, C.c_uint64, C.c_uint64, _i32, _i32,
                                       _f, _f, C.c_int, _p, C.c_size_t, _p, _p, _p, _p]),
@@ -115,7 +108,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and the header diverge
             fn.restype = res
             fn.argtypes = args
-        if lib.ge_version() < 210:
+        if lib.ge_version() < 300:
             raise RuntimeError("libge_hip.so is older than the Python host expects")
         _lib = lib
     return _lib

@@ -8,12 +8,6 @@ int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t
 int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t, int spectral = 0);
 int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
 int complex_max_dim();
-int plan_keys_launch(const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t, void*, int, hipStream_t);
-int plan_flags_launch(const void*, int64_t, int, int32_t*, hipStream_t);
-int plan_heads_launch(const void*, const int32_t*, int64_t, int, int64_t, int32_t*, int32_t*, int32_t*, hipStream_t);
-int plan_scatter_launch(const int64_t*, const int32_t*, const int64_t*, const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int32_t*, int32_t*, hipStream_t);
-int plan_item_counts_launch(const int32_t*, const int32_t*, int64_t, int32_t, int32_t*, int32_t*, hipStream_t);
-int plan_items_launch(const int32_t*, const int32_t*, int64_t, const int64_t*, const int64_t*, const int32_t*, const int32_t*, const int64_t*, int64_t, int32_t, int32_t*, int32_t*, int32_t*, int64_t*, hipStream_t);
 int select_rows_launch(const int32_t*, int64_t, int64_t, uint64_t, uint64_t, int32_t*, hipStream_t);
 int mean_pocket_launch(const float*, int64_t, float*, float*, int32_t*, hipStream_t);
 int copy_if_launch(const float*, float*, int64_t, const int32_t*, hipStream_t);
@@ -25,7 +19,6 @@ int hole_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int hole_max_dim();
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
-int segment_sum_rows_launch(const float*, int64_t, const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int64_t, int32_t, float*, int64_t, int, hipStream_t);
 int gather_rows_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float*, hipStream_t);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
 int complex_score_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, int64_t, float, int, int, float*, hipStream_t);
@@ -167,15 +160,6 @@ int ge_scatter_add_rows(float* table, int64_t N, int32_t d, const int32_t* idx, 
   return scatter_add_rows_launch(table, N, d, idx, val, R, (hipStream_t)stream);
 }
 
-int ge_segment_sum_rows(const float* src, int64_t src_rows, const int32_t* src_idx, const int32_t* order,
-                        const int32_t* begin, const int32_t* len, const int32_t* target, int64_t n_items,
-                        int32_t d, float* out, int64_t out_rows, int32_t accumulate, void* stream) {
-  if (n_items < 0 || src_rows < 0 || !ok_table(out, out_rows, d) || (accumulate != 0 && accumulate != 1)) return GE_EINVAL;
-  if (n_items > 0 && (!src || !order || !begin || !len || !target)) return GE_EINVAL;
-  return segment_sum_rows_launch(src, src_rows, src_idx, order, begin, len, target, n_items, d, out, out_rows,
-                                 accumulate, (hipStream_t)stream);
-}
-
 int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx, int64_t R, float* out,
                    void* stream) {
   if (R < 0 || !ok_table(table, N, d)) return GE_EINVAL;
@@ -248,50 +232,6 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
   if (B > 0 && K > 0 && (!hr || !cand || !out)) return GE_EINVAL;
   return complex_score_1vK_launch(table, N, d, hr, B, cand, K, max_norm, apply_sigmoid, cand_is_head, out,
                                   (hipStream_t)stream);
-}
-
-int ge_plan_keys(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int64_t G, void* key_out,
-                 int key64, void* stream) {
-  if (S < 0 || B < 0 || N <= 0 || G <= 0) return GE_EINVAL;
-  if (S * B > 0 && (!pos || !neg || !key_out)) return GE_EINVAL;
-  if (!key64 && (S * G) * N > (int64_t)INT32_MAX) return GE_EINVAL;   // the key must fit the type the caller sorts
-  return plan_keys_launch(pos, neg, S, B, N, G, key_out, key64, (hipStream_t)stream);
-}
-
-int ge_plan_flags(const void* key_sorted, int64_t n, int key64, int32_t* flag_out, void* stream) {
-  if (n < 0 || n > (int64_t)INT32_MAX - 1 || (n > 0 && (!key_sorted || !flag_out))) return GE_EINVAL;
-  return plan_flags_launch(key_sorted, n, key64, flag_out, (hipStream_t)stream);
-}
-
-int ge_plan_heads(const void* key_sorted, const int32_t* incl, int64_t n, int key64, int64_t div, int32_t* first_pos,
-                  int32_t* quot, int32_t* rem, void* stream) {
-  if (n < 0 || n > (int64_t)INT32_MAX - 1 || div <= 0) return GE_EINVAL;
-  if (n > 0 && (!key_sorted || !incl || !first_pos || !quot || !rem)) return GE_EINVAL;
-  return plan_heads_launch(key_sorted, incl, n, key64, div, first_pos, quot, rem, (hipStream_t)stream);
-}
-
-int ge_plan_scatter(const int64_t* perm, const int32_t* incl, const int64_t* step_start, const int32_t* pos,
-                    const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t* remap, int32_t* order, void* stream) {
-  if (S < 0 || B < 0 || N <= 0) return GE_EINVAL;
-  if (S * B > 0 && (!perm || !incl || !step_start || !pos || !neg || !remap || !order)) return GE_EINVAL;
-  return plan_scatter_launch(perm, incl, step_start, pos, neg, S, B, N, remap, order, (hipStream_t)stream);
-}
-
-int ge_plan_item_counts(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, int32_t max_item, int32_t* n_it,
-                        int32_t* split, void* stream) {
-  if (cap < 0 || max_item <= 0 || (cap > 0 && (!first_pos || !n_runs || !n_it || !split))) return GE_EINVAL;
-  return plan_item_counts_launch(first_pos, n_runs, cap, max_item, n_it, split, (hipStream_t)stream);
-}
-
-int ge_plan_items(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, const int64_t* it_incl,
-                  const int64_t* sp_incl, const int32_t* row_of, const int32_t* bucket, const int64_t* step_start,
-                  int64_t G, int32_t max_item, int32_t* begin, int32_t* length, int32_t* target, int64_t* split_rows,
-                  void* stream) {
-  if (cap < 0 || max_item <= 0 || G <= 0) return GE_EINVAL;
-  if (cap > 0 && (!first_pos || !n_runs || !it_incl || !sp_incl || !begin || !length || !target)) return GE_EINVAL;
-  if (cap > 0 && !row_of && (!bucket || !step_start)) return GE_EINVAL;
-  return plan_items_launch(first_pos, n_runs, cap, it_incl, sp_incl, row_of, bucket, step_start, G, max_item, begin, length,
-                           target, split_rows, (hipStream_t)stream);
 }
 
 int ge_rank_max_dim(void) { return rank_max_dim(); }

@@ -22,91 +22,6 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(
   }
 }
 
-// Segmented row sum, the atomic-free form of the scatter for an index structure that is known ahead
-// of time (the row-sharded path plans it per chunk of steps): work item i owns the source rows
-// order[begin[i] .. begin[i]+len[i]) and ONE destination row.
-//   target[i] >= 0 : out[target] (=|+=) sum      -- the only item of that row: plain store / RMW
-//   target[i] <  0 : atomic add into out[~target] -- the row is split over several items
-// src_idx (optional) marks empty source slots (< 0), as ge_hinge_grad emits them.
-// One wavefront per item.  The item's source list is fetched by the lanes in one coalesced load
-// (and filtered through src_idx) and then broadcast lane by lane with v_readlane, so the row loads
-// form no dependent chain: 4 source rows are in flight per wave; 16-byte lanes when d % 4 == 0.
-template <int VEC, int NV>
-__global__ __launch_bounds__(kBlock) void segment_sum_rows_kernel(
-    const float* __restrict__ src, int64_t src_rows, const int32_t* __restrict__ src_idx,
-    const int32_t* __restrict__ order, const int32_t* __restrict__ begin,
-    const int32_t* __restrict__ len, const int32_t* __restrict__ target, int64_t n_items, int d,
-    float* __restrict__ out, int64_t out_rows, int accumulate) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int nvec = d / VEC;
-  // NV = vectors per lane per pass: NV = 1 covers d <= 256 with 16-byte lanes (few registers, so more
-  // waves per CU hide the item-metadata -> source-list -> row latency chain), NV = 4 covers d <= 1024.
-  constexpr int RIF = 4;  // source rows in flight
-  for (int64_t it = wave; it < n_items; it += nwaves) {
-    const int32_t tg = target[it];
-    const bool multi = tg < 0;
-    const int64_t row = multi ? ~tg : tg;
-    if (row >= out_rows) continue;
-    const int32_t b0 = begin[it], n = len[it];
-    for (int jv = lane; jv < nvec + lane; jv += kWave * NV) {   // uniform trip count (lane-independent)
-      float acc[NV][VEC];
-#pragma unroll
-      for (int u = 0; u < NV; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[u][v] = 0.f;
-      for (int base = 0; base < n; base += kWave) {
-        const int m = min(n - base, (int)kWave);
-        int32_t mine = lane < m ? order[b0 + base + lane] : -1;
-        if (mine >= src_rows) mine = -1;
-        if (mine >= 0 && src_idx && src_idx[mine] < 0) mine = -1;
-        for (int j = 0; j < m; j += RIF) {
-          float t[RIF][NV][VEC];
-#pragma unroll
-          for (int q = 0; q < RIF; ++q) {
-            const int32_t sq = (j + q < m) ? __builtin_amdgcn_readlane(mine, (j + q) & (kWave - 1)) : -1;
-            const float* sp = src + (int64_t)(sq < 0 ? 0 : sq) * d;
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-              const int c = jv + u * kWave;
-              if (sq >= 0 && c < nvec) load_vec<VEC>(sp + c * VEC, t[q][u]);
-              else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) t[q][u][v] = 0.f;
-              }
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < RIF; ++q)
-#pragma unroll
-            for (int u = 0; u < NV; ++u)
-#pragma unroll
-              for (int v = 0; v < VEC; ++v) acc[u][v] += t[q][u][v];
-        }
-      }
-      float* dp = out + row * d;
-#pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        const int c = jv + u * kWave;
-        if (c >= nvec) continue;
-        if (multi) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) atomic_add_f32(dp + c * VEC + v, acc[u][v]);
-        } else {
-          if (accumulate) {
-            float t[VEC];
-            load_vec<VEC>(dp + c * VEC, t);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[u][v] += t[v];
-          }
-          store_vec<VEC>(dp + c * VEC, acc[u]);
-        }
-      }
-    }
-  }
-}
-
 // out[i] = table[idx[i]]  (zeros for idx < 0) -- one wavefront per row.
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(
@@ -235,21 +150,6 @@ int scatter_add_rows_launch(float* table, int64_t N, int32_t d, const int32_t* i
   if (R == 0) return 0;
   const int grid = grid_for(R, kBlock / kWave);
   hipExtLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, N, d, idx, val, R);
-  return launch_status();
-}
-
-int segment_sum_rows_launch(const float* src, int64_t src_rows, const int32_t* src_idx, const int32_t* order,
-                            const int32_t* begin, const int32_t* len, const int32_t* target, int64_t n_items,
-                            int32_t d, float* out, int64_t out_rows, int accumulate, hipStream_t st) {
-  if (d <= 0) return GE_EINVAL;
-  if (n_items == 0) return 0;
-  const int grid = grid_for(n_items, kBlock / kWave);
-#define SEG(V, NVV) hipLaunchKernelGGL((segment_sum_rows_kernel<V, NVV>), dim3(grid), dim3(kBlock), 0, st, src, src_rows, src_idx, order, begin, len, target, n_items, d, out, out_rows, accumulate)
-  if (d % 4 == 0 && d <= 256) SEG(4, 1);
-  else if (d % 4 == 0) SEG(4, 4);
-  else if (d <= 64) SEG(1, 1);
-  else SEG(1, 4);
-#undef SEG
   return launch_status();
 }
 

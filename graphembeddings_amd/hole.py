@@ -291,32 +291,6 @@ def scatter_add_rows(table: torch.Tensor, idx: torch.Tensor, val: torch.Tensor) 
               val.data_ptr(), idx.numel(), _stream())
 
 
-def segment_sum_rows(src: torch.Tensor, src_idx, order: torch.Tensor, begin: torch.Tensor, length: torch.Tensor,
-                     target: torch.Tensor, out: torch.Tensor, accumulate: bool) -> None:
-    """Planned, atomic-free scatter (ge_segment_sum_rows): item i sums src[order[begin[i]:begin[i]+length[i]]]
-    into out[target[i]] (plain store / RMW), or atomically into out[~target[i]] when target[i] < 0."""
-    out = _table(out)
-    for name, t in (("src", src), ("order", order), ("begin", begin), ("length", length), ("target", target)):
-        _need_cuda(t, name)
-        if not t.is_contiguous():
-            raise ValueError(f"{name} must be contiguous")
-    if src.dtype != torch.float32 or src.dim() != 2 or src.shape[1] != out.shape[1]:
-        raise ValueError("src must be fp32 [rows, embedding_dim]")
-    if any(t.dtype != torch.int32 for t in (order, begin, length, target)):
-        raise ValueError("order/begin/length/target must be int32")
-    if not (begin.numel() == length.numel() == target.numel()):
-        raise ValueError("begin, length, target must have one entry per item")
-    sidx = 0
-    if src_idx is not None:
-        _need_cuda(src_idx, "src_idx")
-        if src_idx.dtype != torch.int32 or src_idx.numel() != src.shape[0] or not src_idx.is_contiguous():
-            raise ValueError("src_idx must be contiguous int32 [rows]")
-        sidx = src_idx.data_ptr()
-    _lib.call("ge_segment_sum_rows", src.data_ptr(), src.shape[0], sidx, order.data_ptr(), begin.data_ptr(),
-              length.data_ptr(), target.data_ptr(), target.numel(), out.shape[1], out.data_ptr(), out.shape[0],
-              int(bool(accumulate)), _stream())
-
-
 def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """out[i] = table[idx[i]] (zeros where idx[i] < 0)."""
     table = _table(table)
@@ -444,70 +418,6 @@ def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.int32 or not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous int32")
     return t
-
-
-def plan_sorted_runs(key_sorted: torch.Tensor, div: int):
-    """Runs of equal values in a sorted key array (ge_plan_flags + one scan + ge_plan_heads): returns
-    (incl, first_pos, quot, rem) -- incl[i] - 1 is the run of element i (incl[-1] = number of runs U, still on the
-    device), first_pos[u] the run's first position (first_pos[U] = n), quot/rem[u] = key // div, key % div."""
-    _need_cuda(key_sorted, "key_sorted")
-    if key_sorted.dtype not in (torch.int32, torch.int64) or not key_sorted.is_contiguous():
-        raise ValueError("key_sorted must be contiguous int32 / int64")
-    n, k64, dev = key_sorted.numel(), int(key_sorted.dtype == torch.int64), key_sorted.device
-    flag = torch.empty(n, dtype=torch.int32, device=dev)
-    _lib.call("ge_plan_flags", key_sorted.data_ptr(), n, k64, flag.data_ptr(), _stream())
-    incl = torch.cumsum(flag, 0, dtype=torch.int32)
-    first_pos = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    quot = torch.empty(n, dtype=torch.int32, device=dev)
-    rem = torch.empty(n, dtype=torch.int32, device=dev)
-    _lib.call("ge_plan_heads", key_sorted.data_ptr(), incl.data_ptr(), n, k64, int(div), first_pos.data_ptr(),
-              quot.data_ptr(), rem.data_ptr(), _stream())
-    return incl, first_pos, quot, rem
-
-
-def plan_keys(pos: torch.Tensor, neg: torch.Tensor, n_rows: int, world: int) -> torch.Tensor:
-    """Step-tagged row keys of a chunk (ge_plan_keys): pos, neg [S,B,3] int32 -> [S*6B] int32 (int64 when
-    S * world * n_rows >= 2^31)."""
-    _i32(pos, "pos"), _i32(neg, "neg")
-    S, B = int(pos.shape[0]), int(pos.shape[1])
-    k64 = S * world * n_rows >= 2 ** 31
-    key = torch.empty(S * 6 * B, dtype=torch.int64 if k64 else torch.int32, device=pos.device)
-    _lib.call("ge_plan_keys", pos.data_ptr(), neg.data_ptr(), S, B, int(n_rows), int(world), key.data_ptr(), int(k64), _stream())
-    return key
-
-
-def plan_scatter(perm: torch.Tensor, incl: torch.Tensor, step_start: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor,
-                 n_rows: int):
-    """remap [S,2B,3] (each slot's staged row inside its step, -1 invalid) and order [S*6B] (ge_plan_scatter)."""
-    S, B = int(pos.shape[0]), int(pos.shape[1])
-    if perm.dtype != torch.int64 or step_start.dtype != torch.int64 or not perm.is_contiguous() or not step_start.is_contiguous():
-        raise ValueError("perm / step_start must be contiguous int64")
-    remap = torch.empty(S * 6 * B, dtype=torch.int32, device=pos.device)
-    order = torch.empty(S * 6 * B, dtype=torch.int32, device=pos.device)
-    _lib.call("ge_plan_scatter", perm.data_ptr(), _i32(incl, "incl").data_ptr(), step_start.data_ptr(), pos.data_ptr(),
-              neg.data_ptr(), S, B, int(n_rows), remap.data_ptr(), order.data_ptr(), _stream())
-    return remap.view(S, 2 * B, 3), order
-
-
-def plan_item_counts(first_pos: torch.Tensor, n_runs: torch.Tensor, cap: int, max_item: int):
-    n_it = torch.empty(cap, dtype=torch.int32, device=first_pos.device)
-    split = torch.empty(cap, dtype=torch.int32, device=first_pos.device)
-    _lib.call("ge_plan_item_counts", _i32(first_pos, "first_pos").data_ptr(), _i32(n_runs, "n_runs").data_ptr(), int(cap),
-              int(max_item), n_it.data_ptr(), split.data_ptr(), _stream())
-    return n_it, split
-
-
-def plan_items(first_pos, n_runs, cap, it_incl, sp_incl, row_of, bucket, step_start, world, max_item, n_items, n_split):
-    dev = first_pos.device
-    begin = torch.empty(n_items, dtype=torch.int32, device=dev)
-    length = torch.empty(n_items, dtype=torch.int32, device=dev)
-    target = torch.empty(n_items, dtype=torch.int32, device=dev)
-    split_rows = torch.empty(n_split, dtype=torch.int64, device=dev)
-    _lib.call("ge_plan_items", first_pos.data_ptr(), n_runs.data_ptr(), int(cap), it_incl.data_ptr(), sp_incl.data_ptr(),
-              row_of.data_ptr() if row_of is not None else None, bucket.data_ptr() if bucket is not None else None,
-              step_start.data_ptr() if step_start is not None else None, int(world), int(max_item), begin.data_ptr(),
-              length.data_ptr(), target.data_ptr(), split_rows.data_ptr(), _stream())
-    return begin, length, target, split_rows
 
 
 # ---------------------------------------------------------------- the row-sharded step (csrc/ge_shard.hip)

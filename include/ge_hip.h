@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE_VERSION 210 /* 0.2.1: ge_rank_1vK (model), ge_plan_* */
+#define GE_VERSION 300 /* 0.3.0: ge_shard_* (row-sharded step planned natively), multi-workgroup step sort */
 
 /* argument errors (negative, -errno style) */
 #define GE_EINVAL (-22)  /* bad dimension / null pointer / misaligned buffer */
@@ -144,20 +144,6 @@ int ge_scatter_add_rows(float* table, int64_t N, int32_t d, const int32_t* idx, 
 int ge_gather_rows(const float* table, int64_t N, int32_t d, const int32_t* idx, int64_t R,
                    float* out, void* stream);
 
-/* ge_segment_sum_rows: the atomic-free scatter for an index structure known ahead of time (the
- * row-sharded path plans it once per chunk of steps; same ScatterSub semantics, holE.py:296).
- * Work item i sums the source rows src[order[j]], j in [begin[i], begin[i]+len[i]), skipping
- * order[j] < 0 and -- when src_idx is not NULL -- slots with src_idx[order[j]] < 0 (the empty
- * IndexedSlices slots of ge_hinge_grad), into ONE destination row:
- *   target[i] >= 0: out[target[i]]  = sum (accumulate = 0)  or  += sum (accumulate = 1), plain
- *                   stores -- the caller guarantees no other item targets that row;
- *   target[i] <  0: atomic add into out[~target[i]] (row split over several items; for
- *                   accumulate = 0 the caller zeroes those rows first). */
-int ge_segment_sum_rows(const float* src, int64_t src_rows, const int32_t* src_idx,
-                        const int32_t* order, const int32_t* begin, const int32_t* len,
-                        const int32_t* target, int64_t n_items, int32_t d, float* out,
-                        int64_t out_rows, int32_t accumulate, void* stream);
-
 /* --- corrupt_batch (holE.py:152-153 -> 136-140 -> 97-133) fused with the per-batch host
  * resample of holE.py:343-347.  id_to_type [N] int32 type code per table row (-1 = unknown, the
  * reference's '?' default -> corrupted id -1, holE.py:39); type lists as CSR type_offsets
@@ -225,38 +211,6 @@ int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int
                 const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head, const int32_t* known_off,
                 const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                 float* scores_out, void* stream);
-
-/* --- the exchange planner of the row-sharded step (graphembeddings_amd/sharded.py).  For a chunk of S
- * steps of B positives and B negatives per rank (pos, neg [S,B,3] int32; negatives never depend on the table, so this
- * runs ahead of training): a sort of step-tagged row keys -- done by the host with its device sort -- yields per
- * step the distinct rows to fetch grouped by owner, the position of each of the 6B gradient slots' rows in the
- * staging buffer, and the work items of ge_segment_sum_rows.  These are the single-pass kernels around that sort:
- *   ge_plan_keys         key[s*6B + j] = ((s*G + id % G) * N + id) for the j-th id of step s (pos[s] flattened, then
- *                        neg[s]; ids outside [0,N) alias row 0), int64 or int32 (key64 = 0 needs S*G*N < 2^31)
- *   ge_plan_flags        flag[i] = 1 where a run of equal sorted keys starts
- *   ge_plan_heads        with incl = inclusive scan of flag: per run u its first sorted position first_pos[u]
- *                        (first_pos[U] = n), quot[u] = key / div, rem[u] = key % div
- *   ge_plan_scatter      remap[perm[i]] = run index of sorted position i minus its step's first run (-1 for an invalid
- *                        id), order[i] = position of slot perm[i] in ge_hinge_grad's output
- *   ge_plan_item_counts  per run: ceil(length / max_item) items, and whether it is split (n_runs: device scalar U;
- *                        entries in [U, cap) are zeroed so that scans over the capacity are exact)
- *   ge_plan_items        per run, at it_incl[u] - n_it[u]: begin / length of each item in the sorted order and its
- *                        destination row (row_of[u], or u minus its step's first run when row_of is NULL:
- *                        step = bucket[u] / G), ~row for split runs, whose rows are listed in split_rows
- * Everything is bit-exact integer work; tests compare with the tensor-op planner word for word. */
-int ge_plan_keys(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int64_t G, void* key_out,
-                 int key64, void* stream);
-int ge_plan_flags(const void* key_sorted, int64_t n, int key64, int32_t* flag_out, void* stream);
-int ge_plan_heads(const void* key_sorted, const int32_t* incl, int64_t n, int key64, int64_t div, int32_t* first_pos,
-                  int32_t* quot, int32_t* rem, void* stream);
-int ge_plan_scatter(const int64_t* perm, const int32_t* incl, const int64_t* step_start, const int32_t* pos,
-                    const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t* remap, int32_t* order, void* stream);
-int ge_plan_item_counts(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, int32_t max_item, int32_t* n_it,
-                        int32_t* split, void* stream);
-int ge_plan_items(const int32_t* first_pos, const int32_t* n_runs, int64_t cap, const int64_t* it_incl,
-                  const int64_t* sp_incl, const int32_t* row_of, const int32_t* bucket, const int64_t* step_start,
-                  int64_t G, int32_t max_item, int32_t* begin, int32_t* length, int32_t* target, int64_t* split_rows,
-                  void* stream);
 
 /* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
  * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already

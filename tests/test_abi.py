@@ -18,7 +18,7 @@ def _declared():
 def test_header_declares_expected_entry_points():
     names = _declared()
     for must in ("ge_complex_score", "ge_hole_score", "ge_complex_hinge_step", "ge_hole_hinge_step",
-                 "ge_corrupt_batch", "ge_complex_score_1vK", "ge_hinge_grad", "ge_scatter_add_rows", "ge_segment_sum_rows",
+                 "ge_corrupt_batch", "ge_complex_score_1vK", "ge_hinge_grad", "ge_scatter_add_rows", "ge_shard_plan", "ge_shard_grad", "ge_shard_apply",
                  "ge_gather_rows", "ge_hinge_loss", "ge_version"):
         assert must in names
 
@@ -32,7 +32,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in ge_hip.h but not exported"
     assert set(_declared()) == set(_lib.SYMBOLS), "ctypes table and header diverge"
     loaded = _lib.load()
-    assert loaded.ge_version() >= 210
+    assert loaded.ge_version() >= 300
     assert loaded.ge_max_dim() >= 200
     # pure host helper: workspace = 6B int32 (256-B padded) + 6B*d fp32
     assert loaded.ge_hinge_step_workspace_bytes(4096, 200) == 6 * 4096 * 4 + 6 * 4096 * 200 * 4

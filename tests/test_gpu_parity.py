@@ -330,37 +330,6 @@ def test_gather_and_scatter_rows(H):
         assert np.abs(t.cpu().numpy() - exp).max() < 1e-5
 
 
-def test_segment_sum_rows_matches_scatter(H):
-    """ge_segment_sum_rows with a plan built the way sharded.plan_chunk builds it == scatter-add (np.add.at):
-    overwrite and accumulate modes, empty slots, a row split over several items, d not a multiple of 4."""
-    from graphembeddings_amd.sharded import segment_items
-    rng = np.random.default_rng(11)
-    for d in (200, 50, 7, 260):
-        M, U = 900, 40
-        src = rng.standard_normal((M, d)).astype(np.float32)
-        src_idx = rng.integers(0, 5, M).astype(np.int32) - 1          # 20 % empty slots (-1)
-        dest = rng.integers(1, U, M)
-        dest[:300] = 0                                                  # row 0: 300 slots -> 10 items, atomics
-        dest[300:300 + U - 1] = np.arange(1, U)                         # every row has at least one slot
-        order = np.argsort(dest, kind="stable")
-        cnt = torch.as_tensor(np.bincount(dest, minlength=U)).cuda()
-        it = segment_items(cnt, torch.tensor([0, U]).cuda(), torch.arange(U).cuda(), torch.as_tensor(order).cuda())
-        assert (it.target < 0).sum().item() == 10 and it.split_rows.tolist() == [0]
-        live = src_idx >= 0
-        exp = np.zeros((U, d)); np.add.at(exp, dest[live], src[live].astype(np.float64))
-        out = torch.full((U, d), 9.0, device="cuda")
-        out.index_fill_(0, it.split_rows, 0.0)
-        H.segment_sum_rows(dev(src), dev(src_idx), it.order, it.begin, it.length, it.target, out, False)
-        assert np.abs(out.cpu().numpy() - exp).max() < 2e-5
-        base = rng.standard_normal((U, d)).astype(np.float32)
-        out = dev(base).clone()
-        H.segment_sum_rows(dev(src), None, it.order, it.begin, it.length, it.target, out, True)
-        exp = base.astype(np.float64); np.add.at(exp, dest, src.astype(np.float64))
-        assert np.abs(out.cpu().numpy() - exp).max() < 2e-5
-    with pytest.raises(ValueError):
-        H.segment_sum_rows(dev(src), None, it.order.to(torch.int64), it.begin, it.length, it.target, out, True)
-
-
 # ---------------------------------------------------------------- 1-vs-K (MFMA GEMM)
 @pytest.mark.parametrize("d,B,K", [(200, 37, 129), (200, 256, 256), (50, 5, 70), (128, 130, 64)])
 @pytest.mark.parametrize("cand_is_head", [False, True])
