@@ -321,7 +321,8 @@ __device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, boo
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
   // The whole row is in registers, so its clip scale is known BEFORE anything is stored: the planes hold
-  // t * clip(t) * 2^8 (|.| <= 256: no fp16 overflow whatever the table holds) and the epilogue needs no column scale.
+  // t * clip(t) * 2^8 (|t clip| <= max_norm, or max_norm sqrt(d/2) for one bin of a spectral row: no fp16 overflow
+  // for max_norm <= 8 whatever the table holds) and the epilogue needs no column scale.
   f2 ss2 = {0.f, 0.f};
   static_for<0, kFChunks>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
@@ -344,10 +345,12 @@ __device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, boo
   if (spec) ss = (2.f * ss - corr) / (float)D;
   float inv;
   const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
-  if (half == 0) lds.sB[srow] = bad ? __builtin_nanf("") : 1.0f;   // (the shared epilogue multiplies by it)
   f16_stash<D, 0>(lds, srow, half, 0, 0, R[0], scale);
   f16_stash<D, 0>(lds, srow, half, 0, 1, R[0], scale);
   __syncthreads();
+  // after the barrier: every wave has left the previous tile's epilogue, which reads sB (the scores-only epilogue
+  // has no barrier of its own behind those reads)
+  if (half == 0) lds.sB[srow] = bad ? __builtin_nanf("") : 1.0f;   // (the shared epilogue multiplies by it)
   F16Ops ops[2];
 #pragma unroll
   for (int i = 0; i < 8; ++i) f16_ops_piece<D>(ops[0], lds, wm, wn, li, lh, 0, i);
@@ -475,7 +478,11 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       ssr += __shfl_xor(ssr, 1, kWave);
       float i0, i1;
       const float inv_d = spec ? 1.0f / (float)d : 1.0f;
-      const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1);
+      // The planes hold q * (clip scales) * (1/d for a spectral table) * 2^8.  ComplEx: |q sa| <= 2 max_norm^2.  A spectral
+      // row's clip bounds its Parseval-weighted norm, so ONE bin may reach max_norm sqrt(d/2) and a Hermitian-weighted
+      // product d max_norm^2: the 1/d of the correlation theorem is folded in BEFORE the split (|q sa / d| <= max_norm^2),
+      // which keeps every plane entry below 2^8 * 64 for max_norm <= 8 whatever the table holds.
+      const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d;
       _Float16* ah = lds.Ah + srow * kSA;
       _Float16* am = lds.Am + srow * kSA;
       for (int j = half; j < (k >> 2); j += 2) {                 // pass 2: q * sa * 2^8 -> high halves and remainders
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
             qre[i] = rr[i] * fr[i] + ri[i] * fi[i];
             qim[i] = -(ri[i] * fr[i] - rr[i] * fi[i]);
           }
-          if (spec && !packed) { qre[i] *= 2.f; qim[i] *= 2.f; }   // |q sa| <= 2: still far inside fp16 after the 2^8
+          if (spec && !packed) { qre[i] *= 2.f; qim[i] *= 2.f; }   // Hermitian weight
         }
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
       }
       if (half == 0) {
         for (int c = kFD; c < 16 * kFKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }   // k padding
-        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : inv_d / (kQScale * kQScale);
+        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
         lds.skip[srow] = 0;
         lds.tI[srow] = (MODE != 2 && r < B) ? true_id[r] : -1;
       }
@@ -608,13 +615,16 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         }
       __syncthreads();
       if (t < kRB) {
-        // Bracket of the true candidate's raw score.  A candidate whose raw score x differs from the true one's by
-        // more than wx (in scaled units) has a sigmoid that differs by > 1e-6 * (1 - o(1)), three times what the
-        // roundings of x * sA and of the 4-instruction sigmoid (< 1.5e-7 each side) can move: outside the bracket
-        // the order of the losses is the order of the raw scores.  A saturated sigmoid makes the bracket infinite.
+        // Bracket of the true candidate's raw score.  With g = e (1 - e) the sigmoid's slope at the true score and
+        // w = 1e-6 / g <= 0.1, the slope anywhere inside [xs - w, xs + w] is >= g exp(-w) (the sigmoid is concave on one
+        // side: a first-order bound alone is not enough), so a candidate whose scaled score lies outside has a loss that
+        // differs by >= 0.9e-6, three times what the roundings of x * sA and of the 4-instruction sigmoid
+        // (< 1.5e-7 each side) can move: outside the bracket the order of the losses is the order of the raw scores.
+        // Near saturation (g < 1e-5, |score| > 11.5) no finite bracket gives that margin: it is infinite there and
+        // every candidate of the row takes the exact comparison.
         const float xp = lds.eT[t], sa = lds.sA[t];
-        const float xs = xp * sa, e = rank_sigmoid(xs);
-        const float wx = 1e-6f / (e * (1.0f - e)) + 4e-7f * fabsf(xs);
+        const float xs = xp * sa, e = rank_sigmoid(xs), gs = e * (1.0f - e);
+        const float wx = gs < 1e-5f ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
         const float wq = wx / sa;
         lds.lohi[t] = make_float2(xp - wq, xp + wq);
         lds.eT[t] = e;
@@ -791,7 +801,7 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
     return launch_status();
   };
 #define GE_F16(DD)                                                                                     \
-  if (d == DD && max_norm <= 8.f) {   /* |q| <= 2 max_norm^2, |t clip| <= max_norm: x 2^8 stays inside fp16 */ \
+  if (d == DD && max_norm <= 8.f) {   /* |q sa (1/d)| <= 2 max_norm^2, |t clip| <= max_norm sqrt(d/2): x 2^8 inside fp16 */ \
     if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, DD>, f16_lds_bytes<DD>());                 \
     if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, DD>, f16_lds_bytes<DD>());                  \
     return go16(rank_pipe_kernel<CW, 0, 0, DD>, f16_lds_bytes<DD>());                                  \

@@ -154,6 +154,50 @@ def test_hole_ranks_from_the_spectral_sweep(d):
         E.link_prediction_ranks(emb, test, cand, known, model="hole", fused=False)
 
 
+@pytest.mark.parametrize("d,max_norm", [(200, 2.0), (64, 8.0), (200, 8.0)])
+def test_spectral_sweep_single_bin_rows_above_unit_max_norm(d, max_norm):
+    """The split-precision sweep on a SPECTRAL table with max_norm > 1 and rows whose energy sits in one frequency bin
+    (constant rows: the DC bin; one cosine: one Hermitian-weighted bin).  The clip bounds a row's Parseval norm, so a
+    single bin reaches max_norm sqrt(d/2) and a weighted product d max_norm^2: the 1/d of the correlation theorem
+    must be folded in before the fp16 split or the planes overflow (max_norm > ~1.1 at d = 200).  Losses within 1e-5
+    of the FFT oracle on the real table, ranks equal to the reference heap fed with the kernel's own losses."""
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(d)
+    R, N = 4, 260
+    j = np.arange(d)
+    table = (rng.standard_normal((N, d)) * 0.3).astype(np.float32)
+    table[0:R] = 3.0 * max_norm / np.sqrt(d)                                    # relations: constant rows, norm 3 max_norm
+    table[10:40] = (2.5 * max_norm / np.sqrt(d)) * np.ones((30, d), np.float32)  # constant entities
+    table[40:70] = (4.0 * max_norm * np.sqrt(2.0 / d) * np.cos(2 * np.pi * 3 * j / d)).astype(np.float32)   # one cosine bin
+    table[40:70] *= rng.uniform(0.5, 1.5, (30, 1)).astype(np.float32)
+    table[10:40] *= rng.uniform(0.5, 1.5, (30, 1)).astype(np.float32)
+    spec = H.hole_to_spectral(torch.as_tensor(table).cuda())
+    B = 130
+    test = np.stack([rng.integers(R, 80, B), rng.integers(R, N, B), rng.integers(0, R, B)], 1)
+    cand = np.arange(R, N)
+    c = torch.as_tensor(cand.astype(np.int32)).cuda()
+    t64 = table.astype(np.float64)
+    for side in ("tail", "head"):
+        fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
+        hr = torch.as_tensor(np.stack([test[:, fixed_col], test[:, 2]], 1).astype(np.int32)).cuda()
+        tid = torch.as_tensor(test[:, true_col].astype(np.int32)).cuda()
+        nb, nk, scores = H.rank_candidates(spec, hr, tid, c, cand_is_head=(side == "head"), return_scores=True,
+                                           model="hole_spectral", max_norm=max_norm)
+        nb2, _ = H.rank_candidates(spec, hr, tid, c, cand_is_head=(side == "head"), model="hole_spectral", max_norm=max_norm)
+        assert torch.equal(nb, nb2)                                             # bracket epilogue == exact epilogue
+        scores, nb = scores.cpu().numpy(), nb.cpu().numpy()
+        assert np.isfinite(scores).all()
+        for i, (h, t, r) in enumerate(test):
+            triples = (np.stack([np.full(len(cand), h), cand, np.full(len(cand), r)], 1) if side == "tail"
+                       else np.stack([cand, np.full(len(cand), t), np.full(len(cand), r)], 1))
+            if i < 30:
+                assert np.abs(scores[i] - O.hole_evaluate_triples(triples, t64, max_norm=max_norm)[:, 0]).max() < 1e-5
+            true = test[i, true_col]
+            st = scores[i][true - R]
+            before = int(((scores[i] < st) | ((scores[i] == st) & (cand < true))).sum())
+            assert nb[i] == before, (side, i)
+
+
 @pytest.mark.parametrize("d", [40, 56])
 def test_rank_sweep_edge_shapes_and_bad_ids(d):
     """One row / one candidate, sizes one past the 128-wide tiles, a max_norm below every row norm, ids outside the
