@@ -41,6 +41,9 @@ SYMBOLS = {
     "ge_validation_workspace_bytes": (C.c_size_t, [_i64]),
     "ge_validation_tick": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _i32, _p, C.c_uint64, C.c_uint64, _i32, _i32,
                                       _f, _f, C.c_int, _p, C.c_size_t, _p, _p, _p, _p]),
+    "ge_validation_logloss_workspace_bytes": (C.c_size_t, [_i64, _i32]),
+    "ge_validation_tick_logloss": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _i32, _p, C.c_uint64, C.c_uint64, _i32, _i32,
+                                             _i32, _f, _f, _p, C.c_size_t, _p, _p, _p, _p]),
     "ge_rank_max_dim": (C.c_int, []),
     "ge_complex_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "ge_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p]),

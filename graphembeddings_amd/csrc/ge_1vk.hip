@@ -305,6 +305,175 @@ __global__ __launch_bounds__(kBlock) void score_1vK_fullk_kernel(
   }
 }
 
+// BASELINE config 5 at its own shape (B = 4096 positives x K = 256 shared negatives x d = 200: 256 tiles of 64 x 64,
+// one per CU) is bounded by how fast ONE workgroup gets its 192 rows out of L2 and through 100 fp32 MFMAs per wave,
+// not by throughput.  This variant keeps the whole tile's global loads in flight in TWO batches (complex column
+// groups [0, 16) and [16, ..)), so the MFMAs of the first batch run while the second is still landing, and lays the
+// operands out for 16-byte LDS traffic both ways: Xs[g][row] = 4 consecutive k of a row (g = k / 4; real parts first,
+// then imaginary parts), written with ds_write_b128 by a lane mapping that puts 4 lanes on 64 contiguous bytes of a
+// table row (coalesced) and read back with ONE ds_read_b128 per operand per two MFMAs -- the half-wave lh = 1 takes
+// k = 2, 3 of the group where lh = 0 takes 0, 1 (any k order gives the same dot product as long as both operands
+// agree; the summation order differs from the other kernels' in the last bits only).
+template <int NITA, int NITB>
+__global__ __launch_bounds__(kBlock) void score_1vK_tile_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
+    const int32_t* __restrict__ cand, int64_t K, float max_norm, int apply_sigmoid, int cand_is_head,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = d >> 1, CG = k >> 2;                 // complex column groups of 4 (d % 8 == 0)
+  float4* As = reinterpret_cast<float4*>(smem);      // [2 CG][64]
+  float4* Bs = As + 2 * CG * 64;
+  float* sA = reinterpret_cast<float*>(Bs + 2 * CG * 64);
+  float* sB = sA + 64;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int srow = 16 * w + (lane & 15), gq = lane >> 4;     // staging: 4 lanes (gq) on 64 contiguous bytes of a row
+  // Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md), each with its own L2: the tiles that share
+  // a row block (its 128 rows of Q operands) are renumbered onto ONE XCD, so those rows leave the Infinity Cache once
+  // per row block instead of once per tile (39 MB -> ~10 MB of fabric traffic at 4096 x 256 x 200).  Speed only.
+  const int gx = gridDim.x, T = gx * (int)gridDim.y;
+  const int L = (int)blockIdx.y * gx + (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int V = xcd * (T >> 3) + min(xcd, T & 7) + slot;
+  const int64_t m0 = (int64_t)(V / gx) * 64, n0 = (int64_t)(V % gx) * 64;
+  int32_t fid = -1, rid = -1, cid = -1;
+  bool abad = false, bbad = false;
+  {
+    const int64_t r = m0 + srow;
+    if (r < B) {
+      fid = hr[2 * r]; rid = hr[2 * r + 1];
+      abad = fid < 0 || fid >= N || rid < 0 || rid >= N;
+    }
+    const int64_t c = n0 + srow;
+    if (c < K) { cid = cand[c]; bbad = cid < 0 || cid >= N; }
+  }
+  const bool aok = fid >= 0 && !abad, bok = cid >= 0 && !bbad;
+  const float* frow = table + (int64_t)(aok ? fid : 0) * d;
+  const float* rrow = table + (int64_t)(aok ? rid : 0) * d;
+  const float* crow = table + (int64_t)(bok ? cid : 0) * d;
+  float4 va[NITA][6], vb[NITB][6];
+  // every load is unconditional (a predicated load makes the compiler serialise the whole batch behind waitcnts):
+  // column groups past the row re-read the last one and are dropped in stash(); rows of bad ids / past B or K read
+  // row 0 and are neutralised by their NaN clip scale or by the bounds check of the store
+  auto fetch = [&](int c, float4 (&v)[6]) {
+    const int cc = 4 * min(c, CG - 1);
+    v[0] = *reinterpret_cast<const float4*>(frow + cc);
+    v[1] = *reinterpret_cast<const float4*>(frow + k + cc);
+    v[2] = *reinterpret_cast<const float4*>(rrow + cc);
+    v[3] = *reinterpret_cast<const float4*>(rrow + k + cc);
+    v[4] = *reinterpret_cast<const float4*>(crow + cc);
+    v[5] = *reinterpret_cast<const float4*>(crow + k + cc);
+  };
+#pragma unroll
+  for (int i = 0; i < NITA; ++i) fetch(4 * i + gq, va[i]);
+#pragma unroll
+  for (int i = 0; i < NITB; ++i) fetch(4 * (NITA + i) + gq, vb[i]);
+  float ssf = 0.f, ssr = 0.f, ssc = 0.f;
+  auto dot4 = [](const float4& a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; };
+  auto stash = [&](int c, const float4 (&v)[6]) {
+    if (c >= CG) return;
+    ssf += dot4(v[0]) + dot4(v[1]);
+    ssr += dot4(v[2]) + dot4(v[3]);
+    ssc += dot4(v[4]) + dot4(v[5]);
+    const float fr[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, fi[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+    const float rr[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, ri[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+    float qre[4], qim[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!cand_is_head) {  // q = h * r
+        qre[q] = fr[q] * rr[q] - fi[q] * ri[q];
+        qim[q] = fr[q] * ri[q] + fi[q] * rr[q];
+      } else {              // Re(h * r * conj(t)) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
+        qre[q] = rr[q] * fr[q] + ri[q] * fi[q];
+        qim[q] = -(ri[q] * fr[q] - rr[q] * fi[q]);
+      }
+    }
+    As[c * 64 + srow] = make_float4(qre[0], qre[1], qre[2], qre[3]);
+    As[(CG + c) * 64 + srow] = make_float4(qim[0], qim[1], qim[2], qim[3]);
+    Bs[c * 64 + srow] = v[4];
+    Bs[(CG + c) * 64 + srow] = v[5];
+  };
+  f32x16 acc, acc2;                                  // two independent MFMA chains: real-part groups, imaginary-part groups
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
+  const int li = lane & 31, lh = lane >> 5;
+  // lh = 0 takes k = 0, 1 of a group, lh = 1 takes k = 2, 3: one ds_read_b64 per operand per two MFMAs
+  const float2* ap = reinterpret_cast<const float2*>(As + wm * 32 + li) + lh;
+  const float2* bp = reinterpret_cast<const float2*>(Bs + wn * 32 + li) + lh;
+  // groups [c0, c1) of both halves (real parts g = c, imaginary parts g = CG + c).  The operands of group c + 1 are
+  // requested BEFORE the four MFMAs of group c and consumed after them (scheduling barriers keep the compiler from
+  // sinking the reads to their use, where their latency would sit between the MFMAs); two register sets, no copies.
+  auto ldg = [&](int c, float2 (&o)[4]) {
+    o[0] = ap[c * 128]; o[1] = bp[c * 128]; o[2] = ap[(CG + c) * 128]; o[3] = bp[(CG + c) * 128];
+  };
+  auto mm4 = [&](const float2 (&o)[4]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o[0].x, o[1].x, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(o[2].x, o[3].x, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o[0].y, o[1].y, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(o[2].y, o[3].y, acc2, 0, 0, 0);
+  };
+  auto mma_range = [&](int c0, int c1) {
+    if (c0 >= c1) return;
+    float2 p0[4], p1[4];
+    ldg(c0, p0);
+    for (int c = c0; c < c1; c += 2) {
+      ldg(min(c + 1, c1 - 1), p1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm4(p0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < c1) {
+        ldg(min(c + 2, c1 - 1), p0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm4(p1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // batch A lands first: stash it and run its MFMAs while batch B is still in flight
+#pragma unroll
+  for (int i = 0; i < NITA; ++i) stash(4 * i + gq, va[i]);
+  __syncthreads();
+  const int ga = min(4 * NITA, CG);
+  mma_range(0, ga);
+#pragma unroll
+  for (int i = 0; i < NITB; ++i) stash(4 * (NITA + i) + gq, vb[i]);
+  ssf += __shfl_xor(ssf, 16, kWave); ssf += __shfl_xor(ssf, 32, kWave);
+  ssr += __shfl_xor(ssr, 16, kWave); ssr += __shfl_xor(ssr, 32, kWave);
+  ssc += __shfl_xor(ssc, 16, kWave); ssc += __shfl_xor(ssc, 32, kWave);
+  if (gq == 0) {
+    const float nanv = __builtin_nanf("");
+    float i0, i1;
+    sA[srow] = (abad || fid < 0) ? nanv : clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1);
+    sB[srow] = (bbad || cid < 0) ? nanv : clip_scale(ssc, max_norm, i0);
+  }
+  __syncthreads();
+  mma_range(ga, CG);
+  __syncthreads();                                   // every wave is done reading the operands: As becomes the output tile
+  // epilogue through LDS: C layout (col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 lh) -> Cs[row][65-float stride],
+  // then each lane stores 16 contiguous bytes of a row (4 store instructions per lane instead of 16)
+  float* Cs = smem;
+  const int cl = wn * 32 + li;
+  const float sb = sB[cl];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rl = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+    const float sv = (acc[q] + acc2[q]) * sA[rl] * sb;
+    Cs[rl * 65 + cl] = apply_sigmoid ? rank_sigmoid(sv) : sv;
+  }
+  __syncthreads();
+  const bool k4 = (K & 3) == 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int rl = 16 * p + (t >> 4), c4 = 4 * (t & 15);
+    const int64_t row = m0 + rl, col = n0 + c4;
+    if (row >= B) continue;
+    const float* src = Cs + rl * 65 + c4;
+    if (k4 && col + 3 < K) *reinterpret_cast<float4*>(out + row * K + col) = make_float4(src[0], src[1], src[2], src[3]);
+    else
+      for (int j = 0; j < 4; ++j)
+        if (col + j < K) out[row * K + col + j] = src[j];
+  }
+}
+
 int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                              const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
                              int cand_is_head, float* out, hipStream_t st) {
@@ -324,6 +493,22 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
   const int64_t gy = (B + bm - 1) / bm, gx = (K + bm - 1) / bm;
   if (gy > 65535 || gx > 2147483647LL) return GE_ENOTSUP;
   dim3 grid((unsigned)gx, (unsigned)gy);
+  if (!big && d % 8 == 0 && d <= 256 && reinterpret_cast<uintptr_t>(table) % 16 == 0) {
+    // up to a few hundred 64 x 64 tiles: the whole tile's loads in flight in two batches, 16-byte LDS traffic
+    const size_t lds = sizeof(float4) * (size_t)(4 * (k / 4) * 64) + sizeof(float) * 128;
+    const int cg = k / 4;
+#define LT(NA, NB)                                                                                                        \
+    {                                                                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_tile_kernel<NA, NB>),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      if (e != hipSuccess) return (int)e;                                                                                 \
+      hipLaunchKernelGGL((score_1vK_tile_kernel<NA, NB>), grid, dim3(kBlock), lds, st, table, N, d, hr, B, cand, K,       \
+                         max_norm, apply_sigmoid, cand_is_head, out);                                                     \
+      return launch_status();                                                                                             \
+    }
+    if (cg <= 8) LT(1, 1) else if (cg <= 16) LT(2, 2) else if (cg <= 28) LT(4, 3) else LT(4, 4)
+#undef LT
+  }
   const int KP = (k + 3) & ~3;
   const size_t fullk_lds = sizeof(float) * (size_t)(2 * 64 * (2 * KP + 1) + 128);
   if (!big && fullk_lds <= 150 * 1024) {

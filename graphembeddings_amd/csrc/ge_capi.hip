@@ -142,6 +142,47 @@ int ge_validation_tick(const float* table, int64_t N, int32_t d, const int32_t* 
   return copy_if_launch(table, pocket, N * (int64_t)d, flag, st);
 }
 
+// the same tick for the --log_loss objective (holE.py:194-196, 206-220 on a validation batch): positives with
+// label +1, K corrupted batches with label -1, every loss plus l2 * l2_loss(table)
+size_t ge_validation_logloss_workspace_bytes(int64_t B, int32_t negative_ratio) {
+  if (B <= 0 || negative_ratio < 1) return 0;
+  return ((size_t)B * (3 + 3 + 1 + (size_t)negative_ratio) * 4 + 16 + 255) / 256 * 256 + 256;
+}
+
+int ge_validation_tick_logloss(const float* table, int64_t N, int32_t d, const int32_t* valid, int64_t V, int64_t B,
+                               const int32_t* id_to_type, const int64_t* type_offsets, int32_t n_types,
+                               const int32_t* type_ids, uint64_t seed, uint64_t counter, int32_t padded_size, int32_t mode,
+                               int32_t negative_ratio, float l2, float max_norm, void* workspace, size_t workspace_bytes,
+                               float* mean_out, float* best, float* pocket, void* stream) {
+  if (B <= 0 || V <= 0 || negative_ratio < 1 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (!valid || !id_to_type || !type_offsets || !type_ids || !workspace || !mean_out || !best) return GE_EINVAL;
+  if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return GE_EINVAL;
+  if (workspace_bytes < ge_validation_logloss_workspace_bytes(B, negative_ratio)) return GE_ENOMEM;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t K = negative_ratio, M = (1 + K) * B;
+  float* sumsq = (float*)workspace;                        // [256 B] | pos [B,3] | neg [B,3] | loss [(1+K)B] | flag
+  int32_t* pos = (int32_t*)((char*)workspace + 256);
+  int32_t* neg = pos + 3 * B;
+  float* loss = (float*)(neg + 3 * B);
+  int32_t* flag = (int32_t*)(loss + M);
+  int rc = select_rows_launch(valid, V, B, seed, counter, pos, st);
+  if (rc) return rc;
+  rc = table_sumsq_launch(table, N * (int64_t)d, sumsq, st);
+  if (rc) return rc;
+  rc = complex_score_launch(table, N, d, pos, B, max_norm, 2, loss, st, 0, 1.0f, l2, sumsq);
+  if (rc) return rc;
+  for (int64_t k = 0; k < K; ++k) {
+    rc = corrupt_batch_launch(pos, B, id_to_type, N, type_offsets, n_types, type_ids, seed, counter * (uint64_t)K + (uint64_t)k,
+                              padded_size, mode, neg, st);
+    if (rc) return rc;
+    rc = complex_score_launch(table, N, d, neg, B, max_norm, 2, loss + (1 + k) * B, st, 0, -1.0f, l2, sumsq);
+    if (rc) return rc;
+  }
+  rc = mean_pocket_launch(loss, M, mean_out, best, flag, st);
+  if (rc || !pocket) return rc;
+  return copy_if_launch(table, pocket, N * (int64_t)d, flag, st);
+}
+
 int ge_hinge_grad(const float* rows, int64_t N, int32_t d, const int32_t* pos, const int32_t* neg,
                   int64_t B, float margin, float lr, float max_norm, int model, float* loss,
                   int32_t* grad_idx, float* grad_val, void* stream) {

@@ -375,7 +375,9 @@ class ValidationPocket:
 
     def __init__(self, embeddings: torch.Tensor, validation_triples: torch.Tensor, type_tables: "TypeTables",
                  batch_size: int, *, margin: float = 0.2, model="complex", max_norm: float = 1.0, seed: int = 0,
-                 mode: int = CORRUPT_BATCH_COIN, keep_table: bool = True, capacity: int = 4096):
+                 mode: int = CORRUPT_BATCH_COIN, keep_table: bool = True, capacity: int = 4096, log_loss=None):
+        """log_loss = (negative_ratio, l2_regularization): the tick evaluates the --log_loss objective instead of the hinge
+        (ge_validation_tick_logloss; ComplEx score)."""
         self.emb = _table(embeddings)
         _need_cuda(validation_triples, "validation_triples")
         self.valid = validation_triples.to(torch.int32).contiguous()
@@ -388,13 +390,27 @@ class ValidationPocket:
         self.best = torch.full((), 2.0, dtype=torch.float32, device=dev)     # holE.py:336 pocket_loss = 2.
         self.pocket = torch.empty_like(self.emb) if keep_table else None
         self.hist = torch.zeros(int(capacity), dtype=torch.float32, device=dev)
-        self._ws = torch.empty(max(_lib.load().ge_validation_workspace_bytes(self.B), 256), dtype=torch.uint8, device=dev)
+        self.log_loss = None if log_loss is None else (int(log_loss[0]), float(log_loss[1]))
+        if self.log_loss is not None and self.model != MODEL_COMPLEX:
+            raise NotImplementedError("--log_loss is defined for the ComplEx score (holE.py:191-196)")
+        need = (_lib.load().ge_validation_workspace_bytes(self.B) if self.log_loss is None
+                else _lib.load().ge_validation_logloss_workspace_bytes(self.B, self.log_loss[0]))
+        self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
         self._steps = []        # global step of each tick since the last read()
 
     def tick(self, counter: int, global_step: int) -> None:
         if len(self._steps) >= self.hist.numel():
             raise RuntimeError("ValidationPocket: read() the pending ticks first (capacity %d)" % self.hist.numel())
         tt, i = self.tt, len(self._steps)
+        if self.log_loss is not None:
+            _lib.call("ge_validation_tick_logloss", self.emb.data_ptr(), self.emb.shape[0], self.emb.shape[1],
+                      self.valid.data_ptr(), self.valid.shape[0], self.B, tt.id_to_type.data_ptr(), tt.type_offsets.data_ptr(),
+                      tt.n_types, tt.type_ids.data_ptr(), self.seed & (2**64 - 1), int(counter) & (2**64 - 1), tt.padded_size,
+                      self.mode, self.log_loss[0], self.log_loss[1], self.max_norm, self._ws.data_ptr(), self._ws.numel(),
+                      self.hist.data_ptr() + 4 * i, self.best.data_ptr(),
+                      self.pocket.data_ptr() if self.pocket is not None else None, _stream())
+            self._steps.append(int(global_step))
+            return
         _lib.call("ge_validation_tick", self.emb.data_ptr(), self.emb.shape[0], self.emb.shape[1], self.valid.data_ptr(),
                   self.valid.shape[0], self.B, tt.id_to_type.data_ptr(), tt.type_offsets.data_ptr(), tt.n_types,
                   tt.type_ids.data_ptr(), self.seed & (2**64 - 1), int(counter) & (2**64 - 1), tt.padded_size, self.mode, self.margin, self.max_norm,

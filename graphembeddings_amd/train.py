@@ -12,7 +12,7 @@ which starts at 2.0 (holE.py:329, 357-360); the output directory must not exist 
 checkpoint bundle) are not: the table is saved as `model.ckpt.pt` (embeddings + global_step).
 Between validation ticks the steps are enqueued natively by ge_train_steps (hinge) or
 ge_train_steps_logloss (--log_loss) -- no Python per step.
-Extras: --model hole (README.md:42 score), --seed, --max_steps.
+Extras: --model hole (README.md:42 score), --seed, --max_steps, --checkpoint_seconds.
 """
 from __future__ import annotations
 
@@ -57,6 +57,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--model', choices=['complex', 'hole'], default='complex')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--max_steps', type=int, default=0, help='Stop after this many steps (0 = epoch limit only).')
+    p.add_argument('--checkpoint_seconds', type=float, default=300.,
+                   help='Also write the best table found so far this often inside an epoch (0 = once per epoch only).')
     return p
 
 
@@ -117,16 +119,6 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
         # --log_loss (holE.py:206-220): the same native loop, K corrupted batches per step drawn in the prepare launch
         trainer.enable_log_loss(K, FLAGS.l2_regularization)
 
-    def logloss_validation(batch):
-        """mean of the loss vector for one validation batch with fresh negatives (the table is only read);
-        a device scalar, no host synchronisation."""
-        gs = trainer.global_step
-        vals = [H.evaluate_triples(batch, embeddings, 1, l2_regularization=FLAGS.l2_regularization)]
-        for i in range(K):
-            neg = H.corrupt_batch(tt, data.relation_count, batch, seed=FLAGS.seed ^ 0x5EED, step=gs * K + i)
-            vals.append(H.evaluate_triples(neg, embeddings, -1, l2_regularization=FLAGS.l2_regularization))
-        return torch.cat(vals, 0).mean()
-
     # The reference validates 16 times per epoch and keeps the best table ("pocket", holE.py:351-360).  Reading the
     # validation loss on the host at every tick would stop the device every 7 steps at FB15k / B=4096 (and a
     # dozen tensor-op launches per tick cost more host time than the 7 steps take), so the tick is one native call
@@ -136,31 +128,21 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
     tick = max(1, batch_count // 16)          # guard for the ZeroDivisionError of holE.py:351
     pocket_loss = 2.
     history = []
-    state = {'best_logged': 2.0, 'pocket_step': global_step}
+    state = {'best_logged': 2.0, 'pocket_step': global_step, 'last_write': time.time()}
     vp = None
-    if valid is not None and not FLAGS.log_loss:
+    if valid is not None:
         vp = H.ValidationPocket(embeddings, valid, tt, FLAGS.batch_size, margin=FLAGS.margin, model=eval_model,
-                                seed=FLAGS.seed ^ 0x5EED, capacity=max(64, 2 * (batch_count // tick + 2)))
-    ll = {'pocket': None, 'best': torch.full((), 2.0, device='cuda'), 'vals': []}   # --log_loss: tensor-op ticks
+                                seed=FLAGS.seed ^ 0x5EED, capacity=max(64, 2 * (batch_count // tick + 2)),
+                                log_loss=(K, FLAGS.l2_regularization) if FLAGS.log_loss else None)
 
     def validation_tick():
-        if vp is not None:
-            vp.tick(trainer.global_step, trainer.global_step)
-            return
-        sel = torch.randint(0, valid.shape[0], (FLAGS.batch_size,), device='cuda', generator=gen)
-        vl = logloss_validation(valid[sel].contiguous())
-        if ll['pocket'] is None:
-            ll['pocket'] = torch.empty_like(embeddings)
-        torch.where(vl < ll['best'], embeddings, ll['pocket'], out=ll['pocket'])
-        torch.minimum(vl, ll['best'], out=ll['best'])
-        ll['vals'].append((trainer.global_step, vl))
+        vp.tick(trainer.global_step, trainer.global_step)
 
     def drain():
         """Log the validation ticks since the last call, in order (one synchronisation).  The host sees every loss
         in tick order, so it knows which tick the device pocket holds: the first one with the lowest loss."""
         nonlocal pocket_loss
-        ticks = vp.read() if vp is not None else [(st, float(v)) for st, v in ll['vals']]
-        ll['vals'] = []
+        ticks = vp.read() if vp is not None else []
         for step, vlm in ticks:
             log('\tStep {} Validation Loss: {}...'.format(step, vlm))
             history.append((step, vlm))
@@ -169,9 +151,11 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
                 state['pocket_step'] = step
 
     def write_pocket(epoch):
-        """The checkpoint file follows the device pocket (once per epoch, and at the end)."""
+        """The checkpoint file follows the device pocket: once per epoch, every --checkpoint_seconds in between (the
+        reference saves at every improving tick, holE.py:357-360: a killed run loses at most that much), and at the end."""
         drain()
-        pocket = vp.pocket if vp is not None else ll['pocket']
+        state['last_write'] = time.time()
+        pocket = vp.pocket if vp is not None else None
         if pocket is None or pocket_loss >= state['best_logged']:
             return
         state['best_logged'] = pocket_loss
@@ -198,6 +182,8 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
                 n = min(n, FLAGS.max_steps - (trainer.global_step - global_step))
             if n > 0:
                 trainer.run(n)
+            if FLAGS.checkpoint_seconds > 0 and time.time() - state['last_write'] >= FLAGS.checkpoint_seconds:
+                write_pocket(epoch)
             batch += max(n, 0)
             if FLAGS.max_steps and trainer.global_step - global_step >= FLAGS.max_steps:
                 done = True

@@ -100,6 +100,15 @@ int ge_validation_tick(const float* table, int64_t N, int32_t d, const int32_t* 
                        uint64_t seed, uint64_t counter, int32_t padded_size, int32_t mode, float margin, float max_norm,
                        int model, void* workspace, size_t workspace_bytes, float* mean_out, float* best, float* pocket,
                        void* stream);
+/* The same tick for --log_loss (holE.py:194-196, 206-220 evaluated on a validation batch): the batch with label +1,
+ * negative_ratio corrupted batches (ge_corrupt_batch with step = counter * negative_ratio + k) with label -1, every
+ * loss = log(1 + exp(-y s)) + l2 * sum(table^2) / 2; mean over the (1 + negative_ratio) * B values, pocket as above. */
+size_t ge_validation_logloss_workspace_bytes(int64_t B, int32_t negative_ratio);
+int ge_validation_tick_logloss(const float* table, int64_t N, int32_t d, const int32_t* valid, int64_t V, int64_t B,
+                               const int32_t* id_to_type, const int64_t* type_offsets, int32_t n_types,
+                               const int32_t* type_ids, uint64_t seed, uint64_t counter, int32_t padded_size, int32_t mode,
+                               int32_t negative_ratio, float l2, float max_norm, void* workspace, size_t workspace_bytes,
+                               float* mean_out, float* best, float* pocket, void* stream);
 
 /* --- one SGD step of holE.py:296 on the hinge of holE.py:231: forward of both sides, gradient of
  * SUM_i loss_i through sigmoid, score and the clip, then table[row] -= lr * grad for every

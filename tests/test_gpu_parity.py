@@ -543,6 +543,45 @@ def test_validation_tick_matches_oracle_and_keeps_the_best_table(H):
     assert vp.read() == []
 
 
+def test_logloss_validation_tick_matches_oracle(H):
+    """ge_validation_tick_logloss (hole.ValidationPocket(log_loss=(K, l2))): the --log_loss objective of holE.py:194-196,
+    206-220 on a validation batch -- the batch drawn like the hinge tick's, K corrupted batches with Philox step keys
+    counter * K + k, every loss plus l2 * l2_loss(table) -- against the oracle's logloss_values on the same rows; the
+    pocket takes the table when the mean improves."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    table_h = O.init_table(fb.entity_count, 64, seed=3) * 8.0
+    emb = dev(table_h)
+    valid_h = fb.validation_triples[:5000].astype(np.int32)
+    B, K, l2, seed = 384, 3, 1e-4, 0x1234567
+    vp = H.ValidationPocket(emb, dev(valid_h), tt, B, seed=seed, log_loss=(K, l2))
+
+    def expect(counter, tab):
+        i = np.arange(B, dtype=np.uint64)
+        lo, hi = i & np.uint64(0xFFFFFFFF), i >> np.uint64(32)
+        k0, k1 = (seed & 0xFFFFFFFF) ^ 0x7673656C, (seed >> 32) & 0xFFFFFFFF
+        w0 = O.philox4x32_10(counter & 0xFFFFFFFF, counter >> 32, lo, hi, k0, k1)[0].astype(np.uint64)
+        w1 = O.philox4x32_10(counter & 0xFFFFFFFF, counter >> 32, lo, hi ^ np.uint64(0x80000000), k0, k1)[0].astype(np.uint64)
+        pos = valid_h[(((w1 << np.uint64(32)) | w0) % np.uint64(len(valid_h))).astype(np.int64)]
+        negs = [O.corrupt_batch(pos, id_to_type, offsets, ids, seed, counter * K + k, 1024, 0) for k in range(K)]
+        tri = np.concatenate([pos] + negs, 0)
+        labels = np.concatenate([np.ones(B), -np.ones(K * B)])
+        return float(O.logloss_values(tri, labels, tab.astype(np.float64), l2).mean())
+
+    vp.tick(5, 50)
+    first = emb.clone()
+    emb.mul_(0.25)
+    vp.tick(6, 57)
+    got = vp.read()
+    exp = [expect(5, table_h), expect(6, table_h * np.float32(0.25))]
+    assert [g[0] for g in got] == [50, 57]
+    assert np.abs(np.array([g[1] for g in got]) / np.array(exp) - 1).max() < 2e-6
+    best = int(np.argmin([g[1] for g in got]))
+    assert torch.equal(vp.pocket, [first, emb][best])
+
+
 # ---------------------------------------------------------------- native training loop (ge_train_steps)
 @pytest.mark.parametrize("model,B,d,steps", [("complex", 1024, 200, 70), ("complex", 4096, 200, 6),
                                              ("complex", 100, 50, 9), ("hole", 256, 64, 5), ("hole_direct", 256, 64, 5),

@@ -74,21 +74,6 @@ def test_sharded_planner_index_helpers():
     assert out.tolist() == sorted(out.tolist())
 
 
-def test_segment_items_cuts_long_segments():
-    import torch
-    from graphembeddings_amd import sharded as S
-    cnt = torch.tensor([1, 70, 3, 32, 33])
-    bounds = torch.tensor([0, 2, 5])                             # step 0: segments 0-1, step 1: segments 2-4
-    rows = torch.tensor([7, 8, 0, 1, 2])
-    order = torch.arange(int(cnt.sum()))
-    it = S.segment_items(cnt, bounds, rows, order)
-    assert it.item_start == [0, 4, 8] and it.split_start == [0, 1, 2]
-    assert it.length.tolist() == [1, 32, 32, 6, 3, 32, 32, 1]
-    assert it.begin.tolist() == [0, 1, 33, 65, 71, 74, 106, 138]
-    assert it.target.tolist() == [7, -9, -9, -9, 0, 1, -3, -3]  # split rows are encoded as ~row
-    assert it.split_rows.tolist() == [8, 2]
-
-
 def test_known_index_cells_match_brute_force():
     """evaluate.KnownIndex (device-agnostic tensor code): the per-(128 x 128)-tile lists of known-true cells the
     fused ranking kernel takes, against a brute-force enumeration; duplicates in the known triples count once."""
