@@ -21,6 +21,7 @@ SYMBOLS = {
     "ge_version": (C.c_int, []),
     "ge_max_dim": (C.c_int, []),
     "ge_complex_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
+    "ge_complex_score_strided": (C.c_int, [_p, _i64, _i32, _i64, _p, _i64, _f, C.c_int, _p, _p]),
     "ge_complex_logloss": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, _f, _f, _p, _p, _sz, _p]),
     "ge_hole_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
     "ge_hole_to_spectral": (C.c_int, [_p, _i64, _i32, _p]),

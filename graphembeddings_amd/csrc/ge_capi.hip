@@ -4,7 +4,7 @@
 #include "ge_common.h"
 
 namespace ge {
-int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t, int spectral = 0, float label = 0.f, float l2 = 0.f, const float* table_sumsq = nullptr);
+int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t, int spectral = 0, float label = 0.f, float l2 = 0.f, const float* table_sumsq = nullptr, int64_t ld = 0);
 int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t, int spectral = 0);
 int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
 int complex_max_dim();
@@ -68,6 +68,13 @@ int ge_complex_score(const float* table, int64_t N, int32_t d, const int32_t* tr
   if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
   if (B > 0 && (!triples || !out)) return GE_EINVAL;
   return complex_score_launch(table, N, d, triples, B, max_norm, apply_sigmoid, out, (hipStream_t)stream);
+}
+
+int ge_complex_score_strided(const float* table, int64_t N, int32_t d, int64_t ld, const int32_t* triples, int64_t B,
+                             float max_norm, int apply_sigmoid, float* out, void* stream) {
+  if (B < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm) || ld < d) return GE_EINVAL;
+  if (B > 0 && (!triples || !out)) return GE_EINVAL;
+  return complex_score_launch(table, N, d, triples, B, max_norm, apply_sigmoid, out, (hipStream_t)stream, 0, 0.f, 0.f, nullptr, ld);
 }
 
 int ge_complex_logloss(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B, float label,

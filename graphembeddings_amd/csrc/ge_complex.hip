@@ -24,7 +24,9 @@ template <bool SPEC, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_score_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ triples, int64_t B,
     float max_norm, int apply_sigmoid, float* __restrict__ out, float label, float l2,
-    const float* __restrict__ table_sumsq) {
+    const float* __restrict__ table_sumsq, int64_t ld) {
+  // ld: floats between consecutive rows (= d for the reference's dense [N,d] table; ge_complex_score_strided
+  // measures padded layouts, profiles/r03_padded_rows.txt)
   // apply_sigmoid: 0 raw score, 1 sigmoid (holE.py:198), 2 the --log_loss branch of evaluate_triples
   // (holE.py:194-196): log(1 + exp(-label * score)) + l2 * l2_loss(whole table)
   constexpr int GPW = kWave / LPT;
@@ -41,9 +43,9 @@ __global__ __launch_bounds__(kBlock) void complex_score_kernel(
     const bool bad = bad3(N, hi, ti, ri);
     if (bad) { hi = ti = ri = 0; }
     Row<VEC, NITER> h, t, r;
-    load_row<VEC, LPT, NITER>(table, hi, d, k, nvec, sub, h);
-    load_row<VEC, LPT, NITER>(table, ti, d, k, nvec, sub, t);
-    load_row<VEC, LPT, NITER>(table, ri, d, k, nvec, sub, r);
+    load_row_at<VEC, LPT, NITER>(table + (int64_t)hi * ld, k, nvec, sub, h);
+    load_row_at<VEC, LPT, NITER>(table + (int64_t)ti * ld, k, nvec, sub, t);
+    load_row_at<VEC, LPT, NITER>(table + (int64_t)ri * ld, k, nvec, sub, r);
     const SideFwd f = side_forward<SPEC, VEC, LPT, NITER>(h, t, r, max_norm, sub == 0, wscale);
     if (live && sub == 0) {
       float v = apply_sigmoid == 1 ? f.sig : f.s;
@@ -382,14 +384,16 @@ static bool pick_shape(int d, const void* base, int max_niter, Shape& s) {
 
 int complex_score_launch(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
                          float max_norm, int apply_sigmoid, float* out, hipStream_t st, int spectral, float label,
-                         float l2, const float* table_sumsq) {
+                         float l2, const float* table_sumsq, int64_t ld) {
   Shape s;
+  if (ld <= 0) ld = d;
   if (!pick_shape(d, table, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
+  if (ld < d || (s.vec > 1 && ld % s.vec != 0)) return GE_EINVAL;
   if (B == 0) return 0;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipLaunchKernelGGL((complex_score_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out, label, l2, table_sumsq)
+  hipLaunchKernelGGL((complex_score_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, table, N, d, triples, B, max_norm, apply_sigmoid, out, label, l2, table_sumsq, ld)
   GE_DISPATCH_SPEC(spectral, s, CALL);
 #undef CALL
   return launch_status();

@@ -56,6 +56,10 @@ int ge_max_dim(void);
  * apply_sigmoid=0 returns the raw score.  d must be even.  out: [B] fp32. */
 int ge_complex_score(const float* table, int64_t N, int32_t d, const int32_t* triples, int64_t B,
                      float max_norm, int apply_sigmoid, float* out, void* stream);
+/* The same on a table whose rows are `ld` >= d floats apart (row i at table + i * ld; the reference's table is dense,
+ * ld = d).  Exists to measure padded row layouts (800-byte rows straddle 64-byte sectors; profiles/r03_padded_rows.txt). */
+int ge_complex_score_strided(const float* table, int64_t N, int32_t d, int64_t ld, const int32_t* triples, int64_t B,
+                             float max_norm, int apply_sigmoid, float* out, void* stream);
 
 /* --- evaluate_triples(triple_batch, embeddings, label) in --log_loss mode (holE.py:194-196), forward only:
  * out[i] = log(1 + exp(-label * score_i)) + l2 * sum(table^2) / 2 (tf.nn.l2_loss of the WHOLE table).
