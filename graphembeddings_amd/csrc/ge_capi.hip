@@ -6,7 +6,7 @@
 namespace ge {
 int complex_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t, int spectral = 0, float label = 0.f, float l2 = 0.f, const float* table_sumsq = nullptr, int64_t ld = 0);
 int complex_hinge_loss_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float*, float*, hipStream_t, int spectral = 0);
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0, const int32_t* order = nullptr);
 int complex_max_dim();
 int select_rows_launch(const int32_t*, int64_t, int64_t, uint64_t, uint64_t, int32_t*, hipStream_t);
 int mean_pocket_launch(const float*, int64_t, float*, float*, int32_t*, hipStream_t);

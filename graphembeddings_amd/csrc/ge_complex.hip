@@ -102,17 +102,21 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
 // h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
 // rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
-template <bool SPEC, bool SHARD, int VEC, int LPT, int NITER>
+template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
-    const int32_t* __restrict__ slot_item, float* table_rw, ShardGrad sg) {
+    const int32_t* __restrict__ slot_item, float* table_rw, ShardGrad sg, const int32_t* __restrict__ order) {
   // slot_item + table_rw (training loop only, else null; table_rw aliases `rows`, which is therefore
   // NOT declared __restrict__ const in that instantiation): a slot tagged kSlotDirect is the ONLY
   // gradient slot of its table row in this step -- this pair is the row's only reader and writer -- so
   // the update is applied right here (rows + (-lr*g)) and no gradient row is written for it.
   // SHARD: pos / neg are null; the pair's rows are named by sg.pos_src / sg.neg_src (see ShardGrad).
+  // order (large batches, else null): the pairs sorted by relation row.  Each wave then walks a CONTIGUOUS run of that
+  // order and sums the relation row's gradient of consecutive pairs in registers: one gradient row is written per run
+  // of equal relations (into the slot of the run's last contributing pair; the others' relation slots stay empty)
+  // instead of one per pair -- a quarter of all gradient-row bytes belong to a handful of relation rows.
   constexpr int kSlotDirect = -2;
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
@@ -121,18 +125,50 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
   const int k = d >> 1, nvec = k / VEC;
   const float wscale = 1.0f / (float)d;   // SPEC only: Parseval / correlation-theorem factor
   const float neg_lr = -lr;
-  for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
-    const int64_t g = base + grp;
-    const bool live = g < B;
+  // ORD: this wave's contiguous run [first, last) of the relation order
+  const int64_t per = ORD ? ((B + nwaves - 1) / nwaves + GPW - 1) / GPW * GPW : 0;
+  const int64_t first = wave * per, last = first + per < B ? first + per : B;
+  float racc_re[NITER][VEC], racc_im[NITER][VEC];   // running relation-row gradient of this lane group's run
+#pragma unroll
+  for (int it = 0; it < NITER; ++it)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { racc_re[it][v] = 0.f; racc_im[it][v] = 0.f; }
+  int32_t cur_rel = -1;
+  int64_t cur_slot = -1;                              // >= 0: the slot the running sum will be written to
+  auto flush = [&]() {
+    float* o = grad_val + cur_slot * d;
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+      const int j = sub + it * LPT;
+      if (j < nvec) {
+        store_vec<VEC>(o + j * VEC, racc_re[it]);
+        store_vec<VEC>(o + k + j * VEC, racc_im[it]);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { racc_re[it][v] = 0.f; racc_im[it][v] = 0.f; }
+    }
+    if (sub == 0) grad_idx[cur_slot] = cur_rel;
+    cur_slot = -1;
+  };
+  // the id words of pair g (6: pos + neg triples; SHARD: 3 row sources + the corrupted entity's) and its six tags
+  auto load_ids = [&](int64_t g, int32_t (&raw)[6], int32_t (&tag)[6]) {
+    if (SHARD) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) raw[c] = sg.pos_src[3 * g + c];
+      raw[3] = sg.neg_src[g]; raw[4] = 0; raw[5] = 0;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { raw[c] = pos[3 * g + c]; raw[3 + c] = neg[3 * g + c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tag[c] = slot_item ? slot_item[g * 6 + c] : 0;
+  };
+  auto body = [&](const int64_t g, const bool live, const int32_t (&raw)[6], const int32_t (&tag)[6]) {
     int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
     bool bad;
     if (SHARD) {
       int32_t ns = -1;
-      if (live) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] = sg.pos_src[3 * g + c];
-        ns = sg.neg_src[g];
-      }
+      if (live) { p[0] = raw[0]; p[1] = raw[1]; p[2] = raw[2]; ns = raw[3]; }
       bad = p[0] < 0 || p[1] < 0 || p[2] < 0;
       n[0] = (ns >= 0 && (ns & 1) == 0) ? (ns >> 1) : p[0];
       n[1] = (ns >= 0 && (ns & 1) == 1) ? (ns >> 1) : p[1];
@@ -140,17 +176,11 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
     } else {
       if (live) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+        for (int c = 0; c < 3; ++c) { p[c] = raw[c]; n[c] = raw[3 + c]; }
       }
       bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
     }
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
-    // the six "applied by the producer" tags of this pair, requested together with its ids (not after the forward)
-    int32_t tag[6] = {0, 0, 0, 0, 0, 0};
-    if (slot_item && live) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
-    }
     auto row_ptr = [&](int32_t id) -> const float* {
       return (SHARD && id >= sg.R) ? sg.staged + (int64_t)(id - sg.R) * d : rows + (int64_t)id * d;
     };
@@ -174,8 +204,11 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
       const bool dirN = slot_item && live && !same && tag[3 + X] == kSlotDirect;
       const bool sndP = SHARD && slot_item && live && tag[X] <= -3;
       const bool sndN = SHARD && slot_item && live && !same && tag[3 + X] <= -3;
+      // the relation row of a pair walked in relation order: summed over the run instead of stored per pair
+      const bool accum = ORD && X == 2 && same && !dirP && !sndP;
+      if (accum && live && cur_slot >= 0 && p[2] != cur_rel) flush();
       if (live && sub == 0) {
-        grad_idx[rowP] = (on && !dirP && !sndP) ? p[X] : -1;
+        grad_idx[rowP] = (on && !dirP && !sndP && !accum) ? p[X] : -1;
         grad_idx[rowN] = (on && !same && !dirN && !sndN) ? n[X] : -1;
       }
       if (!on) {
@@ -216,6 +249,11 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
         if (same) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) { pre_[v] += nre_[v]; pim_[v] += nim_[v]; }
+          if (accum) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { racc_re[it][v] += pre_[v]; racc_im[it][v] += pim_[v]; }
+            continue;
+          }
         } else {
           if (dirN) {   // x' = x + (-lr g): same bits as the apply kernel's 0 + g then x + sum
 #pragma unroll
@@ -231,6 +269,43 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
         store_vec<VEC>(gp + j * VEC, pre_);
         store_vec<VEC>(gp + k + j * VEC, pim_);
       }
+      if (accum) { cur_rel = p[2]; cur_slot = rowP; }   // (reached only for hinge-active pairs)
+    }
+  };
+  if constexpr (ORD) {
+    // The run's pair indices come with ONE load per 64 pairs (lane l holds order[first + l]) and every pair's id words
+    // and tags are requested an iteration ahead, while the current pair's rows are in flight: per iteration a wave then
+    // waits for one memory round trip (the rows) instead of three (order -> ids -> rows) -- at 65,536 pairs a wave walks
+    // 4-8 pairs and the chain, not bandwidth, set the kernel's time.  All loads are unconditional (a pair past the run
+    // re-reads pair 0 and is processed as not live).
+    int32_t ord_reg = order[(first + lane < B) ? first + lane : B - 1];
+    int32_t raw[6], tag[6];
+    bool live = first + grp < last;
+    int64_t g = live ? (int64_t)__shfl(ord_reg, grp, kWave) : 0;
+    load_ids(g, raw, tag);
+    for (int64_t base = first; base < last; base += GPW) {
+      const int64_t nb = base + GPW;
+      const int off = (int)((nb - first) & 63);
+      if (off == 0 && nb < last) ord_reg = order[(nb + lane < B) ? nb + lane : B - 1];
+      const int32_t gs = __shfl(ord_reg, off + grp, kWave);
+      const bool live_n = nb + grp < last;
+      const int64_t gn = live_n ? (int64_t)gs : 0;
+      int32_t rawn[6], tagn[6];
+      load_ids(gn, rawn, tagn);
+      body(g, live, raw, tag);
+      g = gn; live = live_n;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { raw[c] = rawn[c]; tag[c] = tagn[c]; }
+    }
+    if (cur_slot >= 0) flush();
+  } else {
+    for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
+      const int64_t g = base + grp;
+      const bool live = g < B;
+      int32_t raw[6] = {0, 0, 0, 0, 0, 0}, tag[6] = {0, 0, 0, 0, 0, 0};
+      if (SHARD) raw[3] = -1;
+      if (live) load_ids(g, raw, tag);     // ids and tags requested together (not after the forward)
+      body(g, live, raw, tag);
     }
   }
 }
@@ -418,7 +493,7 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
                               const int32_t* neg, int64_t B, float margin, float lr, float max_norm,
                               float* loss, int32_t* grad_idx, float* grad_val, hipStream_t st,
                               hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* slot_item, float* table_rw,
-                              int spectral) {
+                              int spectral, const int32_t* order) {
   Shape s;
   if (!pick_shape(d, rows, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   // the gradient rows are written with the same vector width: grad_val must be as aligned as rows
@@ -428,8 +503,9 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, false, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw, ShardGrad{})
-  GE_DISPATCH_SPEC(spectral, s, CALL);
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, false, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw, ShardGrad{}, order)
+  if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
+  else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
 #undef CALL
   return launch_status();
 }
@@ -438,7 +514,7 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
 int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const int32_t* pos_src, const int32_t* neg_src,
                             const int32_t* slot_item, int32_t R, int64_t B, float margin, float lr, float max_norm,
                             float* loss, int32_t* grad_idx, float* grad_val, float* gsum, int spectral, hipStream_t st,
-                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* order) {
   Shape s;
   if (!pick_shape(d, shard, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   for (const void* q : {(const void*)grad_val, (const void*)staged, (const void*)gsum})
@@ -448,8 +524,9 @@ int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const 
   const int grid = grid_for(B, gpb);
   const ShardGrad sg{staged, R, pos_src, neg_src, gsum};
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, true, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg)
-  GE_DISPATCH_SPEC(spectral, s, CALL);
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, true, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg, order)
+  if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
+  else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
 #undef CALL
   return launch_status();
 }

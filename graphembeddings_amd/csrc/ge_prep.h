@@ -26,7 +26,7 @@ __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_
 }
 
 // ------------------------------------------------------------------ prepared-step record (int32 words)
-// hinge (negs = 0):   neg[3B] | slot_item[6B] | pad to 64 | n_sub x { n_items, pad to 64 | items[P][2] | islots[P][16] }
+// hinge (negs = 0):   neg[3B] | slot_item[6B] | (n_sub > 1: order[B]) | pad to 64 | n_sub x { n_items, pad to 64 | items[P][2] | islots[P][16] }
 //   a UNIT is a (pos,neg) pair with 4 sort keys; slot = 6*pair + {0 h+,1 t+,2 r+,3 h-,4 t-,5 r-}.
 // log-loss (negs = K): neg[K][B][3] | pad to 64 | n_sub x { ... }
 //   a UNIT is one of the M = (1+K)B triples (positives first, then the K corrupted batches, holE.py:206-220)
@@ -37,7 +37,7 @@ __host__ __device__ inline int64_t step_row(int64_t first_row, int64_t T, int64_
 // sub-record t holds the items that START in positions [t*P, (t+1)*P) -- an item may run up to 15
 // positions into the next tile.  With one tile the whole sort happens in LDS (train_prepare_kernel).
 struct PrepLayout {
-  int64_t B, negs, units, n_sub, S, P, off_slot, off_sub, sub_stride, off_items, off_islots, stride;
+  int64_t B, negs, units, n_sub, S, P, off_slot, off_order, off_sub, sub_stride, off_items, off_islots, stride;
   int epu;   // sort keys per unit
 };
 __host__ __device__ inline PrepLayout prep_layout(int64_t B, int64_t negs = 0) {
@@ -52,7 +52,10 @@ __host__ __device__ inline PrepLayout prep_layout(int64_t B, int64_t negs = 0) {
   L.S = (s + gran - 1) / gran * gran;
   L.P = L.epu * L.S;
   L.off_slot = 3 * B;
-  L.off_sub = negs > 0 ? (3 * negs * B + 63) / 64 * 64 : (9 * B + 63) / 64 * 64;
+  // hinge steps of more than one tile also carry order[B]: the pairs sorted by relation row (stable), the order
+  // the gradient kernel walks them in so that a wave meets runs of one relation (see complex_hinge_grad_kernel)
+  L.off_order = (negs == 0 && L.n_sub > 1) ? 9 * B : -1;
+  L.off_sub = negs > 0 ? (3 * negs * B + 63) / 64 * 64 : ((L.off_order >= 0 ? 10 : 9) * B + 63) / 64 * 64;
   L.off_items = 64;
   L.off_islots = 64 + 2 * L.P;
   L.sub_stride = 64 + 2 * L.P + kItemCap * L.P;

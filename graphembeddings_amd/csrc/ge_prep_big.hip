@@ -18,6 +18,7 @@
 // Everything is integer work off the training stream's critical path (the look-ahead pipeline runs it on
 // the side stream one chunk of steps ahead).
 #include "ge_prep.h"
+#include <algorithm>
 
 namespace ge {
 
@@ -275,6 +276,39 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
   }
 }
 
+// ---------------------------------------------------------------- pairs in relation order
+// order[B] of a hinge step: the pairs sorted by their relation row (stable).  The gradient kernel walks the pairs
+// in this order, a contiguous run per wave, so that consecutive pairs of a wave share their relation and the
+// relation row's gradient can be summed in registers (complex_hinge_grad_kernel).  Keys (relation << 32 | pair)
+// in tiles of kOrderP, sorted by the same passes as the slot keys.  T == 0: positives given as [steps][B][3].
+constexpr int kOrderP = 16384;
+__global__ __launch_bounds__(kPrepThreads) void order_keys_kernel(
+    const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t N, int n_o,
+    unsigned long long* __restrict__ keys_out) {
+  const int64_t s = blockIdx.x;
+  const int32_t* pos = T > 0 ? triples + 3 * step_row(first_row, T, B, s0 + s) : triples + s * 3 * B;
+  unsigned long long* out = keys_out + (s * n_o + blockIdx.y) * kOrderP;
+  for (int i = threadIdx.x; i < kOrderP; i += kPrepThreads) {
+    const int64_t j = (int64_t)blockIdx.y * kOrderP + i;
+    unsigned long long k = kInvalidKey;
+    if (j < B) {
+      int32_t r = pos[3 * j + 2];
+      if (r < 0 || r >= N) r = (int32_t)N;            // invalid pairs last (they contribute nothing anyway)
+      k = ((unsigned long long)(uint32_t)r << 32) | (uint32_t)j;
+    }
+    out[i] = k;
+  }
+}
+
+__global__ __launch_bounds__(kPrepThreads) void order_write_kernel(
+    const unsigned long long* __restrict__ sorted, int n_o, int64_t B, int64_t stride, int64_t off_order,
+    int32_t* __restrict__ prep) {
+  const unsigned long long* g = sorted + (int64_t)blockIdx.x * n_o * kOrderP;
+  int32_t* order = prep + (int64_t)blockIdx.x * stride + off_order;
+  for (int64_t i = (int64_t)blockIdx.y * kPrepThreads + threadIdx.x; i < B; i += (int64_t)gridDim.y * kPrepThreads)
+    order[i] = (int32_t)(uint32_t)g[i];
+}
+
 // ---------------------------------------------------------------- host
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -322,6 +356,19 @@ int items_launch(const unsigned long long* sorted, int64_t n, const TileGeom& G,
   return launch_status();
 }
 
+// order[B] of n steps into their records (scratch: that of the slot-key sort, which is done with it by now)
+int relation_order_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n, int64_t N,
+                          int32_t* out, int64_t stride, int64_t off_order, void* scratch, hipStream_t st) {
+  const int n_o = (int)((B + kOrderP - 1) / kOrderP);
+  hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)n, (unsigned)n_o), dim3(kPrepThreads), 0, st, triples, T, first_row, B,
+                     s0, N, n_o, sort_scratch_keys(scratch));
+  const unsigned long long* sorted = sort_tiles_launch(scratch, n, n_o, kOrderP, N + 1, st);
+  const int gy = (int)std::min<int64_t>((B + kPrepThreads - 1) / kPrepThreads, 64);
+  hipLaunchKernelGGL(order_write_kernel, dim3((unsigned)n, (unsigned)gy), dim3(kPrepThreads), 0, st, sorted, n_o, B, stride,
+                     off_order, out);
+  return launch_status();
+}
+
 size_t prep_big_scratch_bytes(int64_t B, int64_t negs, int64_t n) {
   const PrepLayout L = prep_layout(B, negs);
   return L.n_sub <= 1 ? 0 : sort_scratch_bytes(n, L.n_sub, L.P);
@@ -336,7 +383,9 @@ int prepare_big_launch(const int32_t* triples, int64_t T, int64_t first_row, int
   hipLaunchKernelGGL(prep_big_keys_kernel, grid, block, 0, st, triples, T, first_row, B, s0, id_to_type, N, type_offsets,
                      n_types, type_ids, seed, global_step0, padded_size, mode, direct, negs, out, sort_scratch_keys(scratch));
   const unsigned long long* sorted = sort_tiles_launch(scratch, n, L.n_sub, L.P, N, st);
-  return items_launch(sorted, n, geom_of(L), direct, out, nullptr, st);
+  const int rc = items_launch(sorted, n, geom_of(L), direct, out, nullptr, st);
+  if (rc || L.off_order < 0) return rc;
+  return relation_order_launch(triples, T, first_row, B, s0, n, N, out, L.stride, L.off_order, scratch, st);
 }
 
 }  // namespace ge

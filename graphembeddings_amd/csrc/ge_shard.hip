@@ -22,7 +22,8 @@
 namespace ge {
 
 int shard_hinge_grad_launch(float*, int32_t, const float*, const int32_t*, const int32_t*, const int32_t*, int32_t, int64_t,
-                            float, float, float, float*, int32_t*, float*, float*, int, hipStream_t, hipEvent_t, hipEvent_t);
+                            float, float, float, float*, int32_t*, float*, float*, int, hipStream_t, hipEvent_t, hipEvent_t,
+                            const int32_t*);
 int apply_items_launch(float*, int, const TileGeom&, const int32_t*, const int32_t*, const float*, int, float*, hipStream_t,
                        hipEvent_t, hipEvent_t);
 size_t sort_scratch_bytes(int64_t n, int64_t n_sub, int64_t P);
@@ -30,6 +31,8 @@ unsigned long long* sort_scratch_keys(void* scratch);
 const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st);
 int items_launch(const unsigned long long* sorted, int64_t n, const TileGeom& G, int direct, int32_t* out, const ShardOut* so,
                  hipStream_t st);
+int relation_order_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n, int64_t N,
+                          int32_t* out, int64_t stride, int64_t off_order, void* scratch, hipStream_t st);
 
 // ---------------------------------------------------------------- requester: keys
 // grid (S, tiles).  neg must differ from pos in at most one of (head, tail) -- what ge_corrupt_batch produces;
@@ -141,7 +144,9 @@ int shard_plan_launch(const int32_t* pos, const int32_t* neg, int64_t S, int64_t
   const unsigned long long* sorted = sort_tiles_launch(scratch, S, L.n_sub, L.P, (int64_t)R * (G + 1), st);
   hipLaunchKernelGGL(shard_heads_kernel, grid, block, 0, st, sorted, (int)L.P, (int)L.n_sub, R, G, rank, tile_heads, counts);
   const ShardOut so{R, B, pos_src, neg_src, req_row, tile_heads};
-  return items_launch(sorted, S, geom_of(L), /*direct=*/1, records, &so, st);
+  const int rc = items_launch(sorted, S, geom_of(L), /*direct=*/1, records, &so, st);
+  if (rc || L.off_order < 0) return rc;
+  return relation_order_launch(pos, 0, 0, B, 0, S, N, records, L.stride, L.off_order, scratch, st);
 }
 
 int shard_grad_launch(float* shard, int32_t d, const float* staged, const int32_t* pos_src, const int32_t* neg_src,
@@ -149,7 +154,7 @@ int shard_grad_launch(float* shard, int32_t d, const float* staged, const int32_
                       float* loss, int32_t* gidx, float* gval, float* gsum, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const PrepLayout L = prep_layout(B);
   return shard_hinge_grad_launch(shard, d, staged, pos_src, neg_src, record + L.off_slot, R, B, margin, lr, max_norm, loss,
-                                 gidx, gval, gsum, spectral, st, e0, e1);
+                                 gidx, gval, gsum, spectral, st, e0, e1, L.off_order >= 0 ? record + L.off_order : nullptr);
 }
 
 int shard_apply_launch(float* shard, int32_t d, const int32_t* record, int64_t B, const int32_t* gidx, const float* gval,

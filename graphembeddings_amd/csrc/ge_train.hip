@@ -30,7 +30,7 @@
 
 namespace ge {
 
-int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0);
+int complex_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr, const int32_t* slot_item = nullptr, float* table_rw = nullptr, int spectral = 0, const int32_t* order = nullptr);
 int hole_hinge_grad_launch(const float*, int64_t, int32_t, const int32_t*, const int32_t*, int64_t, float, float, float, float*, int32_t*, float*, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int scatter_add_rows_launch(float*, int64_t, int32_t, const int32_t*, const float*, int64_t, hipStream_t, hipEvent_t = nullptr, hipEvent_t = nullptr);
 int corrupt_batch_launch(const int32_t*, int64_t, const int32_t*, int64_t, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t*, hipStream_t);
@@ -222,7 +222,10 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
 // sequence; tiles never share a single-item row (the sort is over the whole step, ge_prep_big.hip).
 // Lane l owns columns l, l+64, ... (256 contiguous bytes per wave instruction for loads, stores and
 // atomics alike).
-template <int NJ>
+// COND (steps of several tiles): a gradient row is requested only if its slot is live -- there most relation slots are
+// empty (their sum sits in the run's last slot, complex_hinge_grad_kernel) and bandwidth, not the length of the
+// dependent-load chain, is what the kernel runs out of; one-tile steps request every listed row together with the flags.
+template <int NJ, bool COND>
 __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
     int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val, int split,
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int c = lane + kWave * j;
-          v[q][j] = (c < d) ? src[c] : 0.f;
+          v[q][j] = (c < d && (!COND || on[q])) ? src[c] : 0.f;
         }
       }
 #pragma unroll
@@ -299,8 +302,12 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
   const int grid = grid_for(G.P, kBlock / kWave);  // at most P items per tile
   const int nj = (d + kWave - 1) / kWave;
   const dim3 g((unsigned)grid, (unsigned)G.n_sub);
-#define LA(NJ) hipExtLaunchKernelGGL(apply_sorted_kernel<NJ>, g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2)
-  if (nj <= 1) LA(1); else if (nj <= 2) LA(2); else if (nj <= 4) LA(4); else if (nj <= 8) LA(8); else if (nj <= 16) LA(16);
+#define LA(NJ)                                                                                                             \
+  {                                                                                                                        \
+    if (G.n_sub > 1) hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, true>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
+    else hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, false>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
+  }
+  if (nj <= 1) LA(1) else if (nj <= 2) LA(2) else if (nj <= 4) LA(4) else if (nj <= 8) LA(8) else if (nj <= 16) LA(16)
   else return GE_ENOTSUP;
 #undef LA
   return launch_status();
@@ -323,9 +330,10 @@ bool train_fast_ok(int64_t B, int32_t d) { return B >= 1 && B <= (int64_t)1 << 2
 static int64_t prep_chunk_steps(int64_t B, int64_t negs = 0) {
   const int64_t u = negs > 0 ? (1 + negs) * B : B;
   int64_t c = (32 * kSub) / (u < kSub ? kSub : u);
-  // the multi-tile sort is a sequence of short launches (2 per radix pass): its latency is the same for 2 steps
-  // or 8, so a chunk holds at least 8 steps (19 MB of records each at B = 65,536) until records pass ~1 GB
-  const int64_t floor_steps = u <= 4 * 65536 ? 8 : 2;
+  // the multi-tile sorts (slot keys, relation order) are ~16 short launches whose latency is the same for 2 steps
+  // or 16: a chunk holds enough steps that the sequence (~0.3-0.5 ms) hides behind them -- 16 up to 32,768 units
+  // (42 us steps at 16,384), 8 up to 262,144 (19 MB of records each at B = 65,536), 2 beyond
+  const int64_t floor_steps = u <= 32768 ? 16 : u <= 4 * 65536 ? 8 : 2;
   return c < floor_steps ? floor_steps : c;
 }
 
@@ -612,7 +620,8 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
     const bool dir = fast && direct;
     rc = hole_direct ? hole_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1)
                      : complex_hinge_grad_launch(table, N, d, pos, neg, B, margin, lr, max_norm, loss_s, gidx, gval, st, g0, g1,
-                                                 dir ? step_rec + L.off_slot : nullptr, dir ? table : nullptr, spectral ? 1 : 0);
+                                                 dir ? step_rec + L.off_slot : nullptr, dir ? table : nullptr, spectral ? 1 : 0,
+                                                 (fast && L.off_order >= 0) ? step_rec + L.off_order : nullptr);
     if (rc) return rc;
     if (fast) rc = apply_sorted_launch(table, d, L, step_rec, gidx, gval, st, a0, a1);
     else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
