@@ -102,8 +102,114 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_loss_kernel(
 // h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
 // rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
-template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER>
+template <bool SPEC, int VEC, int LPT, int NITER>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
+    const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
+    const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
+    float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
+    const int32_t* __restrict__ slot_item, float* table_rw) {
+  // slot_item + table_rw (training loop only, else null; table_rw aliases `rows`, which is therefore
+  // NOT declared __restrict__ const in that instantiation): a slot tagged kSlotDirect is the ONLY
+  // gradient slot of its table row in this step -- this pair is the row's only reader and writer -- so
+  // the update is applied right here (rows + (-lr*g)) and no gradient row is written for it.
+  constexpr int kSlotDirect = -2;
+  constexpr int GPW = kWave / LPT;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int k = d >> 1, nvec = k / VEC;
+  const float wscale = 1.0f / (float)d;   // SPEC only: Parseval / correlation-theorem factor
+  const float neg_lr = -lr;
+  for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
+    const int64_t g = base + grp;
+    const bool live = g < B;
+    int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { p[c] = pos[3 * g + c]; n[c] = neg[3 * g + c]; }
+    }
+    const bool bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
+    if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    // the six "applied by the producer" tags of this pair, requested together with its ids (not after the forward)
+    int32_t tag[6] = {0, 0, 0, 0, 0, 0};
+    if (slot_item && live) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
+    }
+    Row<VEC, NITER> xp[3], xn[3];
+#pragma unroll
+    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, p[X], d, k, nvec, sub, xp[X]);
+#pragma unroll
+    for (int X = 0; X < 3; ++X) load_row<VEC, LPT, NITER>(rows, n[X], d, k, nvec, sub, xn[X]);
+    const SideFwd fp = side_forward<SPEC, VEC, LPT, NITER>(xp[0], xp[1], xp[2], max_norm, sub == 0, wscale);
+    const SideFwd fn = side_forward<SPEC, VEC, LPT, NITER>(xn[0], xn[1], xn[2], max_norm, sub == 0, wscale);
+    const float pre = fp.sig - fn.sig + margin;
+    const bool on = live && !bad && (pre >= 0.f);  // MaximumGrad: x >= y
+    if (live && sub == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
+    const float cp = fp.sig * (1.f - fp.sig), cn = -fn.sig * (1.f - fn.sig);
+#pragma unroll
+    for (int X = 0; X < 3; ++X) {
+      const bool same = p[X] == n[X];
+      const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
+      const bool dirP = slot_item && live && tag[X] == kSlotDirect;
+      const bool dirN = slot_item && live && !same && tag[3 + X] == kSlotDirect;
+      if (live && sub == 0) {
+        grad_idx[rowP] = (on && !dirP) ? p[X] : -1;
+        grad_idx[rowN] = (on && !same && !dirN) ? n[X] : -1;
+      }
+      if (!on) continue;
+      const RowCoef kp = row_coef(cp, fp, X, max_norm, neg_lr);
+      const RowCoef kn = row_coef(cn, fn, X, max_norm, neg_lr);
+      float* gp = dirP ? table_rw + (int64_t)p[X] * d : grad_val + rowP * d;
+      float* gn = dirN ? table_rw + (int64_t)n[X] * d : grad_val + rowN * d;
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        const int j = sub + it * LPT;
+        if (j >= nvec) continue;
+        float pre_[VEC], pim_[VEC], nre_[VEC], nim_[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float gre, gim;
+          graw<SPEC, VEC, NITER>(X, xp[0], xp[1], xp[2], it, v, sub == 0, gre, gim);
+          pre_[v] = kp.alpha * gre + kp.beta * xp[X].re[it][v];
+          pim_[v] = kp.alpha * gim + kp.beta * xp[X].im[it][v];
+          graw<SPEC, VEC, NITER>(X, xn[0], xn[1], xn[2], it, v, sub == 0, gre, gim);
+          nre_[v] = kn.alpha * gre + kn.beta * xn[X].re[it][v];
+          nim_[v] = kn.alpha * gim + kn.beta * xn[X].im[it][v];
+        }
+        if (same) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { pre_[v] += nre_[v]; pim_[v] += nim_[v]; }
+        } else {
+          if (dirN) {   // x' = x + (-lr g): same bits as the apply kernel's 0 + g then x + sum
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { nre_[v] += xn[X].re[it][v]; nim_[v] += xn[X].im[it][v]; }
+          }
+          store_vec<VEC>(gn + j * VEC, nre_);
+          store_vec<VEC>(gn + k + j * VEC, nim_);
+        }
+        if (dirP) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { pre_[v] += xp[X].re[it][v]; pim_[v] += xp[X].im[it][v]; }
+        }
+        store_vec<VEC>(gp + j * VEC, pre_);
+        store_vec<VEC>(gp + k + j * VEC, pim_);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- hinge + row gradients, planned steps
+// The same kernel for the steps that come with a plan beyond the direct tags: SHARD (two row stores, the row-sharded
+// step) and / or ORD (pairs walked in relation order, large batches).  The one-tile training step and the single-step
+// API keep the kernel above unchanged: its code is tuned to the 4096-pair step, where every instruction between
+// the id loads and the row loads shows.
+// d(sum_i L_i)/d(raw rows), pre-multiplied by -lr, as IndexedSlices (6 slots per pair:
+// h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
+// rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
+// Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
+template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER>
+__global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
@@ -160,8 +266,13 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
 #pragma unroll
       for (int c = 0; c < 3; ++c) { raw[c] = pos[3 * g + c]; raw[3 + c] = neg[3 * g + c]; }
     }
+    if (slot_item) {       // one test around all six: per-element tests make the compiler wait after every load
 #pragma unroll
-    for (int c = 0; c < 6; ++c) tag[c] = slot_item ? slot_item[g * 6 + c] : 0;
+      for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) tag[c] = 0;
+    }
   };
   auto body = [&](const int64_t g, const bool live, const int32_t (&raw)[6], const int32_t (&tag)[6]) {
     int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
@@ -503,9 +614,12 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, false, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw, ShardGrad{}, order)
-  if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
-  else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
+  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw)
+#define CALLO(V, L, NI) \
+  hipExtLaunchKernelGGL((complex_hinge_grad_plan_kernel<SP, false, true, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw, ShardGrad{}, order)
+  if (order) { GE_DISPATCH_SPEC(spectral, s, CALLO); }
+  else { GE_DISPATCH_SPEC(spectral, s, CALL); }
+#undef CALLO
 #undef CALL
   return launch_status();
 }
@@ -524,7 +638,7 @@ int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const 
   const int grid = grid_for(B, gpb);
   const ShardGrad sg{staged, R, pos_src, neg_src, gsum};
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_kernel<SP, true, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg, order)
+  hipExtLaunchKernelGGL((complex_hinge_grad_plan_kernel<SP, true, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg, order)
   if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
   else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
 #undef CALL
