@@ -135,7 +135,7 @@ def train_step_hbm_roofline(d, B=SHARDED_BATCH, n_entities=1_200_000, steps=48):
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
     kern = {}
-    for k, name in ((1, "complex_hinge_grad_kernel"), (2, "apply_sorted_kernel")):
+    for k, name in ((1, "complex_hinge_grad_plan_kernel"), (2, "apply_sorted_kernel")):
         ev = H.Events(2 * steps)
         tr.run(steps, events=ev.handles, ev_kernel=k)
         torch.cuda.synchronize()
@@ -144,17 +144,21 @@ def train_step_hbm_roofline(d, B=SHARDED_BATCH, n_entities=1_200_000, steps=48):
     loss = float(tr.last_loss.mean())
     tr.close()
     del emb, tr, dtri
-    alg = {"step": (72 * d + 28) * B, "complex_hinge_grad_kernel": (24 * d + 28) * B, "apply_sorted_kernel": 48 * d * B}
+    alg = {"step": (72 * d + 28) * B, "complex_hinge_grad_plan_kernel": (24 * d + 28) * B}
     traffic = {k: pmc_traffic(k, f"synthetic_d{d}_b{B}") for k in kern}
     return {"workload": f"synthetic {n_entities} entities, complex d={d}, batch={B}, native loop (ge_train_steps), 1 GPU",
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "table_mb": round(data.entity_count * d * 4 / 1e6, 1),
             "ms_per_step": el * 1e3, "scored_triples_per_s": 2.0 * B / el,
             "achieved": alg["step"] / el / 1e9, "frac": alg["step"] / el / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_step": alg["step"],
-            "kernels": {k: {"kernel_ms": v, "algorithmic_bytes_per_launch": alg[k], "achieved": alg[k] / (v * 1e-3) / 1e9,
-                            "frac": alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": traffic[k]["hbm_bytes_per_launch"] if traffic[k] else None,
-                            "traffic_source": traffic[k]["source"] if traffic[k] else None} for k, v in kern.items()},
+            # per kernel: its time and its measured HBM traffic (committed PMC summary).  An algorithmic figure is given
+            # for the gradient kernel only: the 48d of the update's read-modify-writes are mostly done inside it (sole-slot
+            # rows) or merged before the apply kernel runs, so a per-kernel share of them would be arbitrary.
+            "kernels": {k: dict({"kernel_ms": v, "traffic": traffic[k]["hbm_bytes_per_launch"] if traffic[k] else None,
+                                 "traffic_source": traffic[k]["source"] if traffic[k] else None},
+                                **({"algorithmic_bytes_per_launch": alg[k], "achieved": alg[k] / (v * 1e-3) / 1e9,
+                                    "frac": alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} if k in alg else {}))
+                        for k, v in kern.items()},
             "final_mean_hinge": round(loss, 6)}
 
 
