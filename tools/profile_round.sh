@@ -26,7 +26,7 @@ with open(f"{out}/{tag}_onevk_profile.txt", "w") as f:
         for row in csv.DictReader(open(p)):
             if "1vK" in row["Name"] or "score" in row["Name"]:
                 f.write(f"{row['Name'][:70]}  calls {row['Calls']}  avg_ns {row['AverageNs']}  min_ns {row['MinNs']}  max_ns {row['MaxNs']}\n")
-    f.write(open(f"{out}/{tag}_onevk.log").read().strip().splitlines()[-1] + "\n")
+    f.write([l for l in open(f"{out}/{tag}_onevk.log").read().splitlines() if l.startswith("ok")][-1] + "\n")
 PY
 echo "onevk done"
 bash tools/profile_rank.sh ${TAG} > "$OUT/${TAG}_prof_rank.log" 2>&1
