@@ -49,6 +49,9 @@ def parse():
                     help="N>1: which triples a rank trains -- those whose head row it owns (default), or a random share")
     ap.add_argument("--plan-group", action="store_true",
                     help="N>1: run the exchange planner's collectives on a second communicator (untested on hardware)")
+    ap.add_argument("--peer-mapped", action="store_true",
+                    help="N>1 EXPERIMENT: map the other ranks' shards by IPC and read their rows in place instead of the row "
+                         "all-to-all (two cross-rank barriers per step); rehearsed on one device only, needs peer access on hardware")
     ap.add_argument("--entities", type=int, default=1_200_000)
     ap.add_argument("--triples", type=int, default=30_000_000)
     return ap.parse_args()

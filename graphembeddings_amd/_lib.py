@@ -62,8 +62,8 @@ SYMBOLS = {
     "ge_train_prepare_steps": (C.c_int, [_p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _u64, _u64, _i32, _i32,
                                          C.c_int, _p, _sz, _p]),
     "ge_shard_plan_workspace_bytes": (_sz, [_i64, _i64]),
-    "ge_shard_plan": (C.c_int, [_p, _p, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
-    "ge_shard_grad": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i64, _i64, _i32, _f, _f, _f, C.c_int, _p, _p, _p, _p, _p]),
+    "ge_shard_plan": (C.c_int, [_p, _p, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _sz, _i32, _p]),
+    "ge_shard_grad": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i64, _i64, _i32, _f, _f, _f, C.c_int, _p, _p, _p, _p, _p, _p]),
     "ge_shard_apply": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
     "ge_shard_owner_record_words": (_i64, [_i64]),
     "ge_shard_owner_workspace_bytes": (_sz, [_i64, _i64]),

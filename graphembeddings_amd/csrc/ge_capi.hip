@@ -35,8 +35,8 @@ size_t train_prepare_bytes(int64_t, int64_t);
 size_t train_logloss_ws_bytes(int64_t, int32_t, int32_t);
 int train_logloss_run(float*, int64_t, int32_t, const int32_t*, int64_t, int64_t, int64_t, int64_t, const int32_t*, const int64_t*, int32_t, const int32_t*, uint64_t, uint64_t, int32_t, int32_t, int32_t, float, float, float, float, float, float*, int, int32_t*, void*, size_t, void*, hipStream_t);
 size_t shard_plan_scratch_bytes(int64_t, int64_t);
-int shard_plan_launch(const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, void*, hipStream_t);
-int shard_grad_launch(float*, int32_t, const float*, const int32_t*, const int32_t*, const int32_t*, int32_t, int64_t, float, float, float, int, float*, int32_t*, float*, float*, hipStream_t, hipEvent_t, hipEvent_t);
+int shard_plan_launch(const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int32_t, int32_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, void*, int, hipStream_t);
+int shard_grad_launch(float*, int32_t, const float*, const int32_t*, const int32_t*, const int32_t*, int32_t, int64_t, float, float, float, int, float*, int32_t*, float*, float*, const float* const*, int, hipStream_t, hipEvent_t, hipEvent_t);
 int shard_apply_launch(float*, int32_t, const int32_t*, int64_t, const int32_t*, const float*, int32_t, float*, hipStream_t, hipEvent_t, hipEvent_t);
 int64_t shard_owner_record_words(int64_t);
 size_t shard_owner_scratch_bytes(int64_t, int64_t);
@@ -386,25 +386,29 @@ size_t ge_shard_plan_workspace_bytes(int64_t B, int64_t S) { return (B <= 0 || S
 
 int ge_shard_plan(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t G, int32_t rank,
                   int32_t* records, int32_t* pos_src, int32_t* neg_src, int32_t* req_row, int32_t* counts,
-                  void* workspace, size_t workspace_bytes, void* stream) {
+                  void* workspace, size_t workspace_bytes, int32_t peer_mapped, void* stream) {
   if (S < 0 || B <= 0 || B > ((int64_t)1 << 24) || !shard_ok(N, G, rank)) return GE_EINVAL;
+  if (peer_mapped && (G > 8 || ((N + G - 1) / G) * (G + 1) >= ((int64_t)1 << 30))) return GE_EINVAL;
   if (S == 0) return 0;
   if (!pos || !neg || !records || !pos_src || !neg_src || !req_row || !counts || !workspace) return GE_EINVAL;
   if (workspace_bytes < shard_plan_scratch_bytes(B, S)) return GE_ENOMEM;
-  return shard_plan_launch(pos, neg, S, B, N, G, rank, records, pos_src, neg_src, req_row, counts, workspace, (hipStream_t)stream);
+  return shard_plan_launch(pos, neg, S, B, N, G, rank, records, pos_src, neg_src, req_row, counts, workspace, peer_mapped, (hipStream_t)stream);
 }
 
 int ge_shard_grad(float* shard, int64_t rows_local, int32_t d, const float* staged, int64_t n_staged, const int32_t* pos_src,
                   const int32_t* neg_src, const int32_t* record, int64_t B, int64_t N, int32_t G, float margin, float lr,
-                  float max_norm, int model, float* loss, int32_t* grad_idx, float* grad_val, float* gsum, void* stream) {
+                  float max_norm, int model, float* loss, int32_t* grad_idx, float* grad_val, float* gsum,
+                  const float* const* peer_shards, void* stream) {
   if (B < 0 || !ok_table(shard, rows_local, d) || !max_norm_ok(max_norm) || !shard_ok(N, G, 0)) return GE_EINVAL;
+  if (peer_shards && (staged || G > 8)) return GE_EINVAL;
   if (model != GE_MODEL_COMPLEX && model != GE_MODEL_HOLE_SPECTRAL) return GE_ENOTSUP;   // hole: keep the shard spectral
   if (B == 0) return 0;
   const int64_t R = (N + G - 1) / G;
-  if (rows_local > R || n_staged < 0 || (n_staged > 0 && (!staged || !gsum))) return GE_EINVAL;
+  if (rows_local > R || n_staged < 0 || (n_staged > 0 && ((!staged && !peer_shards) || !gsum))) return GE_EINVAL;
   if (!pos_src || !neg_src || !record || !loss || !grad_idx || !grad_val) return GE_EINVAL;
   return shard_grad_launch(shard, d, staged, pos_src, neg_src, record, (int32_t)R, B, margin, lr, max_norm,
-                           model == GE_MODEL_HOLE_SPECTRAL, loss, grad_idx, grad_val, gsum, (hipStream_t)stream, nullptr, nullptr);
+                           model == GE_MODEL_HOLE_SPECTRAL, loss, grad_idx, grad_val, gsum, peer_shards, G, (hipStream_t)stream,
+                           nullptr, nullptr);
 }
 
 int ge_shard_apply(float* shard, int64_t rows_local, int32_t d, const int32_t* record, int64_t B, int64_t N, int32_t G,

@@ -293,7 +293,12 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
     }
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
     auto row_ptr = [&](int32_t id) -> const float* {
-      return (SHARD && id >= sg.R) ? sg.staged + (int64_t)(id - sg.R) * d : rows + (int64_t)id * d;
+      if (SHARD && id >= sg.R) {
+        if (sg.staged) return sg.staged + (int64_t)(id - sg.R) * d;
+        const int32_t o = id / sg.R - 1;                 // peer-mapped: the owner's shard, read in place
+        return sg.peer[o & (kMaxPeers - 1)] + (int64_t)(id - sg.R * (o + 1)) * d;
+      }
+      return rows + (int64_t)id * d;
     };
     Row<VEC, NITER> xp[3], xn[3];
 #pragma unroll
@@ -628,7 +633,7 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
 int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const int32_t* pos_src, const int32_t* neg_src,
                             const int32_t* slot_item, int32_t R, int64_t B, float margin, float lr, float max_norm,
                             float* loss, int32_t* grad_idx, float* grad_val, float* gsum, int spectral, hipStream_t st,
-                            hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* order) {
+                            hipEvent_t ev_start, hipEvent_t ev_stop, const int32_t* order, const float* const* peers, int n_peers) {
   Shape s;
   if (!pick_shape(d, shard, 2, s)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;
   for (const void* q : {(const void*)grad_val, (const void*)staged, (const void*)gsum})
@@ -636,7 +641,11 @@ int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const 
   if (B == 0) return 0;
   const int gpb = (kBlock / kWave) * (kWave / s.lpt);
   const int grid = grid_for(B, gpb);
-  const ShardGrad sg{staged, R, pos_src, neg_src, gsum};
+  ShardGrad sg{staged, R, pos_src, neg_src, gsum, {}};
+  if (peers) {
+    if (staged || n_peers > kMaxPeers) return GE_EINVAL;
+    for (int i = 0; i < kMaxPeers; ++i) sg.peer[i] = i < n_peers ? peers[i] : nullptr;
+  }
 #define CALL(V, L, NI) \
   hipExtLaunchKernelGGL((complex_hinge_grad_plan_kernel<SP, true, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg, order)
   if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }

@@ -109,12 +109,17 @@ __device__ __forceinline__ SideFwd side_forward(const Row<VEC, NITER>& h, const 
 // this rank's shard (read in place), R + u is row u of the staging buffer that holds the rows fetched from
 // the other owners -- and a gradient row with a tag <= -3 is the only one of its (remote) row in this step: it
 // is stored straight into row -3 - tag of the send buffer `gsum` instead of being queued for the reduction.
+// Peer-mapped variant (an experiment): staged == null and the other owners' shards are mapped
+// into this process (IPC); a source >= R is then the VIRTUAL row R (1 + owner) + local row and is read from
+// peer[owner] directly.  Gradient sums still travel through gsum.
+constexpr int kMaxPeers = 8;
 struct ShardGrad {
   const float* staged;
   int32_t R;
   const int32_t* pos_src;   // [B][3]
   const int32_t* neg_src;   // [B]
   float* gsum;
+  const float* peer[kMaxPeers];
 };
 
 __device__ __forceinline__ bool bad3(int64_t N, int32_t a, int32_t b, int32_t c) {

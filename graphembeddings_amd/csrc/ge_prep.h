@@ -90,6 +90,8 @@ struct ShardOut {
   int32_t* neg_src;             // [S][B]   (source << 1 | column) of the corrupted entity, -1 = none of its own
   int32_t* req_row;             // [S][n_sub * P]  row u's index in its owner's shard
   const int32_t* tile_heads;    // [S][n_sub] distinct remote rows that START in each tile
+  int32_t peer;                 // 1: pos_src / neg_src name another owner's row by its VIRTUAL row R (1 + owner) + local row
+                                //    (peer-mapped shards are read directly), not by its staging index R + u
 };
 
 // radix-sort geometry for row ids < N: n_pass passes of `bits` bits (>= 6: one counter per thread in the scan)

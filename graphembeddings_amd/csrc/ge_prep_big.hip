@@ -213,7 +213,10 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
         const bool valid = kk != kInvalidKey;
         const uint32_t row = (uint32_t)(kk >> 32);
         const bool head = valid && (base + i == 0 || (uint32_t)(kp >> 32) != row);
-        const bool sole = direct && head && !(kn != kInvalidKey && (uint32_t)(kn >> 32) == row);
+        // (peer-mapped shards: an own row may be read by another rank's gradient kernel at this very moment, so
+        // it is never updated by the producing pair; it waits for the apply kernel behind the cross-rank barrier)
+        const bool sole = direct && head && !(kn != kInvalidKey && (uint32_t)(kn >> 32) == row) &&
+                          !(SHARD && so.peer && row < (uint32_t)so.R);
         const bool rhead = SHARD && head && row >= (uint32_t)so.R;
         const int rs = max(wave_incl_max(head ? base + i : -1, lane), mcarry);
         mcarry = __shfl(rs, kWave - 1, kWave);
@@ -248,14 +251,16 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
       if (SHARD && valid) {
         const bool remote = row >= (uint32_t)so.R;
         const int u = u0 + (inc_loc[r] >> 16);
+        uint32_t src = row;                             // where the pair reads this row from
         if (remote) {
           if ((rhead_mask >> r) & 1u) so.req_row[(int64_t)blockIdx.x * total + u] = (int32_t)(row % (uint32_t)so.R);
+          if (!so.peer) src = (uint32_t)so.R + (uint32_t)u;
           row = (uint32_t)so.R + (uint32_t)u;
           tag = -3 - u;
         }
         const uint32_t pair = slot / 6u, X = slot - pair * 6u;
-        if (X < 3) so.pos_src[((int64_t)blockIdx.x * so.B + pair) * 3 + X] = (int32_t)row;
-        else so.neg_src[(int64_t)blockIdx.x * so.B + pair] = (int32_t)((row << 1) | (X - 3u));
+        if (X < 3) so.pos_src[((int64_t)blockIdx.x * so.B + pair) * 3 + X] = (int32_t)src;
+        else so.neg_src[(int64_t)blockIdx.x * so.B + pair] = (int32_t)((src << 1) | (X - 3u));
       }
       if (sole) slot_item[slot] = tag;
       if ((start_mask >> r) & 1u) {

@@ -23,7 +23,7 @@ namespace ge {
 
 int shard_hinge_grad_launch(float*, int32_t, const float*, const int32_t*, const int32_t*, const int32_t*, int32_t, int64_t,
                             float, float, float, float*, int32_t*, float*, float*, int, hipStream_t, hipEvent_t, hipEvent_t,
-                            const int32_t*);
+                            const int32_t*, const float* const*, int);
 int apply_items_launch(float*, int, const TileGeom&, const int32_t*, const int32_t*, const float*, int, float*, hipStream_t,
                        hipEvent_t, hipEvent_t);
 size_t sort_scratch_bytes(int64_t n, int64_t n_sub, int64_t P);
@@ -132,7 +132,7 @@ size_t shard_plan_scratch_bytes(int64_t B, int64_t S) {
 
 int shard_plan_launch(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t G, int32_t rank,
                       int32_t* records, int32_t* pos_src, int32_t* neg_src, int32_t* req_row, int32_t* counts,
-                      void* scratch, hipStream_t st) {
+                      void* scratch, int peer, hipStream_t st) {
   const PrepLayout L = prep_layout(B);
   const int32_t R = (int32_t)((N + G - 1) / G);
   const dim3 grid((unsigned)S, (unsigned)L.n_sub), block(kPrepThreads);
@@ -143,7 +143,7 @@ int shard_plan_launch(const int32_t* pos, const int32_t* neg, int64_t S, int64_t
                      sort_scratch_keys(scratch));
   const unsigned long long* sorted = sort_tiles_launch(scratch, S, L.n_sub, L.P, (int64_t)R * (G + 1), st);
   hipLaunchKernelGGL(shard_heads_kernel, grid, block, 0, st, sorted, (int)L.P, (int)L.n_sub, R, G, rank, tile_heads, counts);
-  const ShardOut so{R, B, pos_src, neg_src, req_row, tile_heads};
+  const ShardOut so{R, B, pos_src, neg_src, req_row, tile_heads, peer ? 1 : 0};
   const int rc = items_launch(sorted, S, geom_of(L), /*direct=*/1, records, &so, st);
   if (rc || L.off_order < 0) return rc;
   return relation_order_launch(pos, 0, 0, B, 0, S, N, records, L.stride, L.off_order, scratch, st);
@@ -151,10 +151,12 @@ int shard_plan_launch(const int32_t* pos, const int32_t* neg, int64_t S, int64_t
 
 int shard_grad_launch(float* shard, int32_t d, const float* staged, const int32_t* pos_src, const int32_t* neg_src,
                       const int32_t* record, int32_t R, int64_t B, float margin, float lr, float max_norm, int spectral,
-                      float* loss, int32_t* gidx, float* gval, float* gsum, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+                      float* loss, int32_t* gidx, float* gval, float* gsum, const float* const* peers, int n_peers,
+                      hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const PrepLayout L = prep_layout(B);
   return shard_hinge_grad_launch(shard, d, staged, pos_src, neg_src, record + L.off_slot, R, B, margin, lr, max_norm, loss,
-                                 gidx, gval, gsum, spectral, st, e0, e1, L.off_order >= 0 ? record + L.off_order : nullptr);
+                                 gidx, gval, gsum, spectral, st, e0, e1, L.off_order >= 0 ? record + L.off_order : nullptr,
+                                 peers, n_peers);
 }
 
 int shard_apply_launch(float* shard, int32_t d, const int32_t* record, int64_t B, const int32_t* gidx, const float* gval,

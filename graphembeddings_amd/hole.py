@@ -437,7 +437,7 @@ def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------- the row-sharded step (csrc/ge_shard.hip)
-def shard_plan(pos: torch.Tensor, neg: torch.Tensor, n_rows: int, world: int, rank: int):
+def shard_plan(pos: torch.Tensor, neg: torch.Tensor, n_rows: int, world: int, rank: int, peer_mapped: bool = False):
     """ge_shard_plan for S steps: pos, neg [S,B,3] int32 global ids -> (records [S,W], pos_src [S,B,3], neg_src [S,B],
     req_row [S,cap], counts [S,world]) -- see include/ge_hip.h."""
     _i32(pos, "pos"), _i32(neg, "neg")
@@ -452,20 +452,29 @@ def shard_plan(pos: torch.Tensor, neg: torch.Tensor, n_rows: int, world: int, ra
     need = int(_lib.load().ge_shard_plan_workspace_bytes(B, S))
     ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     _lib.call("ge_shard_plan", pos.data_ptr(), neg.data_ptr(), S, B, int(n_rows), int(world), int(rank), records.data_ptr(),
-              pos_src.data_ptr(), neg_src.data_ptr(), req_row.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+              pos_src.data_ptr(), neg_src.data_ptr(), req_row.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
+              int(bool(peer_mapped)), _stream())
     return records, pos_src, neg_src, req_row, counts
 
 
 def shard_grad(shard: torch.Tensor, staged, pos_src, neg_src, record, B: int, n_rows: int, world: int, lr: float,
-               margin: float, model, max_norm: float, grad_idx: torch.Tensor, grad_val: torch.Tensor, gsum) -> torch.Tensor:
-    """ge_shard_grad: one step's fused gather/score/hinge/grad on the shard (in place) + the staged rows; returns loss [B]."""
+               margin: float, model, max_norm: float, grad_idx: torch.Tensor, grad_val: torch.Tensor, gsum,
+               peer_shards=None) -> torch.Tensor:
+    """ge_shard_grad: one step's fused gather/score/hinge/grad on the shard (in place) + the staged rows; returns loss [B].
+    peer_shards (experiment): the `world` shards as tensors mapped into this process -- the other owners' rows are
+    then read in place and `staged` is None (the plan must have been built with peer_mapped=True)."""
+    import ctypes as C
     shard = _table(shard)
-    n_staged = 0 if staged is None else int(staged.shape[0])
+    n_staged = (0 if gsum is None else int(gsum.shape[0])) if peer_shards is not None else (0 if staged is None else int(staged.shape[0]))
     loss = torch.empty(B, dtype=torch.float32, device=shard.device)
-    _lib.call("ge_shard_grad", shard.data_ptr(), shard.shape[0], shard.shape[1], staged.data_ptr() if n_staged else None,
+    peers = None
+    if peer_shards is not None:
+        peers = (C.c_void_p * len(peer_shards))(*[t.data_ptr() for t in peer_shards])
+    _lib.call("ge_shard_grad", shard.data_ptr(), shard.shape[0], shard.shape[1],
+              staged.data_ptr() if (peers is None and n_staged) else None,
               n_staged, pos_src.data_ptr(), neg_src.data_ptr(), record.data_ptr(), int(B), int(n_rows), int(world),
               float(margin), float(lr), float(max_norm), _MODELS[model], loss.data_ptr(), grad_idx.data_ptr(),
-              grad_val.data_ptr(), gsum.data_ptr() if n_staged else None, _stream())
+              grad_val.data_ptr(), gsum.data_ptr() if n_staged else None, peers, _stream())
     return loss
 
 

@@ -67,8 +67,11 @@ class HipKernels:
     def gather_rows(self, table, idx):
         return self.h.gather_rows(table, idx)
 
+    peer_shards = None     # set by ShardedTrainer(peer_mapped=True): the shards of all ranks, mapped into this process
+
     def plan_requester(self, pos, neg, n_rows, world, rank) -> RequesterPlan:
-        records, pos_src, neg_src, req_row, counts = self.h.shard_plan(pos, neg, n_rows, world, rank)
+        records, pos_src, neg_src, req_row, counts = self.h.shard_plan(pos, neg, n_rows, world, rank,
+                                                                         peer_mapped=self.peer_shards is not None)
         return RequesterPlan(S=int(pos.shape[0]), B=int(pos.shape[1]), counts=counts, req_row=req_row,
                              data=(records, pos_src, neg_src, n_rows, world))
 
@@ -85,7 +88,7 @@ class HipKernels:
         records, pos_src, neg_src, n_rows, world = plan.data
         gi, gv = self._workspace(plan.B, shard.shape[1], shard.device)
         return self.h.shard_grad(shard, staged, pos_src[s], neg_src[s], records[s], plan.B, n_rows, world, lr, margin, model,
-                                 max_norm, gi, gv, gsum)
+                                 max_norm, gi, gv, gsum, peer_shards=self.peer_shards)
 
     def apply(self, shard, plan, s, gsum):
         records, _, _, n_rows, world = plan.data
@@ -163,7 +166,14 @@ class StepStats:
 
 class ShardedTrainer:
     def __init__(self, shard: torch.Tensor, n_rows: int, type_tables, *, margin=0.2, model="complex",
-                 max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None, plan_group=None):
+                 max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None, plan_group=None, peer_mapped=False):
+        """peer_mapped (EXPERIMENT, one node, world <= 8, HipKernels): every rank maps the other ranks' shards into
+        its address space (CUDA IPC handles exchanged once) and the gradient kernel reads the other owners' rows IN
+        PLACE over the fabric: no gather, no row all-to-all, no staging buffer.  What it costs instead: two
+        stream-ordered cross-rank barriers per step (nobody may update rows another rank is still reading; nobody may
+        read rows whose owner has not finished the previous step's updates).  Gradient sums still go back by
+        all-to-all.  Rehearsed with the ranks sharing one device; on real peers it additionally needs peer access
+        between the devices to be enabled, which this code does not do: do not enable it on hardware unverified."""
         self.shard = shard
         self.N = int(n_rows)
         self.d = int(shard.shape[1])
@@ -192,8 +202,29 @@ class ShardedTrainer:
         # in issue order, so the look-ahead plan's two exchanges then wait behind the all-to-alls of the chunk that
         # is training (the host blocks in the plan's size read-back until that chunk is done).
         self.plan_group = plan_group if plan_group is not None else group
+        self.peer_mapped = bool(peer_mapped) and self.world > 1
+        if self.peer_mapped:
+            self._map_peer_shards()
         self._side = torch.cuda.Stream(device=shard.device) if shard.is_cuda else None
         self._pending = None    # (positives, first global step, plan) built ahead for the next run_pipelined call
+
+    def _map_peer_shards(self):
+        """Exchange CUDA IPC handles of the shards (torch's own reduction: hipIpcGetMemHandle / OpenMemHandle) and keep
+        the mapped tensors alive; the kernel backend gets their addresses."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        if self.world > 8 or not hasattr(self.k, "peer_shards"):
+            raise ValueError("peer_mapped needs world <= 8 and the HIP kernel backend")
+        fn, args = reduce_tensor(self.shard)
+        box = [None] * self.world
+        dist.all_gather_object(box, (fn, args), group=self.group)
+        self._peer_tensors = [self.shard if r == self.rank else box[r][0](*box[r][1]) for r in range(self.world)]
+        self.k.peer_shards = self._peer_tensors
+        self._sync_word = torch.zeros(1, dtype=torch.float32, device=self.shard.device)
+
+    def _rank_barrier(self):
+        """Stream-ordered barrier across the ranks: a one-word all-reduce (it completes on a rank only after every
+        rank has reached it on ITS stream; the host is not blocked)."""
+        dist.all_reduce(self._sync_word, group=self.group)
 
     # -- exchange helpers ---------------------------------------------------------------------
     def _a2a(self, send: torch.Tensor, send_counts, recv_counts, group=None) -> torch.Tensor:
@@ -253,11 +284,17 @@ class ShardedTrainer:
         staged = gsum = None
         if self.world > 1:
             sc, rc = plan.sc[s], plan.rc[s]
-            req = plan.req_all[plan.req_start[s]:plan.req_start[s + 1]]
-            rows_out = self.k.gather_rows(self.shard, req)              # owners gather ...
-            staged = self._a2a(rows_out, rc, sc)                        # ... rows arrive in staging order
-            gsum = torch.zeros_like(staged)                             # rows with > 16 slots add atomically
+            if self.peer_mapped:
+                self._rank_barrier()                                    # every owner has finished the previous step's updates
+                gsum = torch.zeros(int(sum(sc)), self.d, dtype=self.shard.dtype, device=self.shard.device)
+            else:
+                req = plan.req_all[plan.req_start[s]:plan.req_start[s + 1]]
+                rows_out = self.k.gather_rows(self.shard, req)          # owners gather ...
+                staged = self._a2a(rows_out, rc, sc)                    # ... rows arrive in staging order
+                gsum = torch.zeros_like(staged)                         # rows with > 16 slots add atomically
         loss = self.k.grad(self.shard, staged, plan.req, s, lr, self.margin, self.model, self.max_norm, gsum)
+        if self.peer_mapped:
+            self._rank_barrier()                                        # nobody still reads rows that are about to change
         self.k.apply(self.shard, plan.req, s, gsum)                     # own rows in place, staged rows -> gsum
         if self.world > 1:
             recv_g = self._a2a(gsum, sc, rc)                            # sums back to the owners

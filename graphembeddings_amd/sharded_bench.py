@@ -73,7 +73,8 @@ def run(args, emit=True):
     # streams have no cross-rank launch order, the classic multi-communicator hang, and this path has not
     # run on a multi-GPU node yet; on ONE communicator every rank enqueues in program order.
     plan_group = dist.new_group(backend=backend) if (world > 1 and getattr(args, "plan_group", False)) else None
-    tr = S.ShardedTrainer(shard, N, tt, margin=0.2, model=args.model, seed=0, plan_group=plan_group)
+    tr = S.ShardedTrainer(shard, N, tt, margin=0.2, model=args.model, seed=0, plan_group=plan_group,
+                          peer_mapped=bool(getattr(args, "peer_mapped", False)))
     batch_count = args.triples // (B * world)
     decay_steps = 32.0 * batch_count
     ev = H.Events(2)
@@ -148,7 +149,8 @@ def run(args, emit=True):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {n_ent} entities / {args.triples} triples, {args.model} d={d}, "
                                    f"table row-sharded (id % N) over {world} GPU(s), triples partitioned by head owner, "
-                                   f"RCCL all-to-all of ids/rows/gradient sums",
+                                   + ("rows read in place from IPC-mapped peer shards, all-to-all of gradient sums"
+                                      if tr.peer_mapped else "RCCL all-to-all of ids/rows/gradient sums"),
                        "batch_per_gpu": B, "embedding_dim": d, "table_rows": N,
                        "table_mb_per_gpu": round(rows * d * 4 / 1e6, 1), "parallelism": f"row-shard x{world}",
                        "per_gpu_value": 2.0 * B * K / el, "unique_rows_per_step": stats.unique_rows,

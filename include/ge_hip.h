@@ -330,18 +330,22 @@ int ge_train_prepare_steps(const int32_t* triples, int64_t T, int64_t first_row,
  *   pos_src [S,B,3], neg_src [S,B]: where each pair reads its rows (own row, or R + u; neg_src = source << 1 |
  *     column of the corrupted entity, -1 when it has no row of its own; pos_src -1 = invalid pair);
  *   req_row [S,4*Bt] (Bt = B rounded up to the record's tile size: layout[1] * layout[2]): entry u = staged row u's
- *     index in its owner's shard, grouped by owner; counts [S,G]: rows requested from each owner. */
+ *     index in its owner's shard, grouped by owner; counts [S,G]: rows requested from each owner.
+ *   peer_mapped = 1 (experiment, G <= 8): pos_src / neg_src name another owner's row by R * (1 + owner) + local row
+ *     instead of R + u -- for ge_shard_grad with peer_shards (HOST array of the G shards' device addresses, mapped
+ *     into this process; entry `rank` unused), which reads those rows in place and takes no staging buffer. */
 size_t ge_shard_plan_workspace_bytes(int64_t B, int64_t S);
 int ge_shard_plan(const int32_t* pos, const int32_t* neg, int64_t S, int64_t B, int64_t N, int32_t G, int32_t rank,
                   int32_t* records, int32_t* pos_src, int32_t* neg_src, int32_t* req_row, int32_t* counts,
-                  void* workspace, size_t workspace_bytes, void* stream);
+                  void* workspace, size_t workspace_bytes, int32_t peer_mapped, void* stream);
 /* One step's fused gather -> clip -> score -> sigmoid -> hinge -> gradient rows on two row stores: the shard
  * (rows < R, in place; sole-slot rows are updated here) and `staged` [n_staged,d], the rows fetched from the
  * other owners.  gsum [n_staged,d] receives the gradient rows tagged -3 - u.  model: GE_MODEL_COMPLEX or
  * GE_MODEL_HOLE_SPECTRAL.  loss [B], grad_idx [6B], grad_val [6B,d] as for ge_hinge_grad. */
 int ge_shard_grad(float* shard, int64_t rows_local, int32_t d, const float* staged, int64_t n_staged, const int32_t* pos_src,
                   const int32_t* neg_src, const int32_t* record, int64_t B, int64_t N, int32_t G, float margin, float lr,
-                  float max_norm, int model, float* loss, int32_t* grad_idx, float* grad_val, float* gsum, void* stream);
+                  float max_norm, int model, float* loss, int32_t* grad_idx, float* grad_val, float* gsum,
+                  const float* const* peer_shards, void* stream);
 /* The step's work items: own rows get ONE read-modify-write each, staged rows their sum in gsum (which must be
  * zero beforehand: rows with more than 16 slots combine atomically). */
 int ge_shard_apply(float* shard, int64_t rows_local, int32_t d, const int32_t* record, int64_t B, int64_t N, int32_t G,

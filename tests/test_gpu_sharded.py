@@ -53,7 +53,7 @@ def _problem(name, world):
     return id_to_type, offsets, ids, table, tri, B, steps, padded
 
 
-def _worker(rank, world, port, q, name):
+def _worker(rank, world, port, q, name, peer_mapped=False):
     import torch.distributed as dist
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -70,7 +70,7 @@ def _worker(rank, world, port, q, name):
             del table
             # the planner's collectives on their own group, as sharded_bench does; run_pipelined builds the
             # next chunk's plan on a side stream while the current chunk's kernels run
-            tr = S.ShardedTrainer(shard, n_rows, tt, margin=0.2, seed=13, plan_group=dist.new_group())
+            tr = S.ShardedTrainer(shard, n_rows, tt, margin=0.2, seed=13, plan_group=dist.new_group(), peer_mapped=peer_mapped)
             # step s uses rows [(s*world + rank)*B, +B) of the triple array
             mine = torch.stack([torch.as_tensor(tri[(s * world + rank) * B:(s * world + rank + 1) * B])
                                 for s in range(steps)], 0).cuda()
@@ -88,8 +88,11 @@ def _worker(rank, world, port, q, name):
         raise
 
 
-@pytest.mark.parametrize("name,world", [("fb15k", 2), ("fb15k", 4), ("config4", 2), ("one_owner", 2)])
-def test_sharded_real_kernels_match_c_port(name, world):
+@pytest.mark.parametrize("name,world,peer", [("fb15k", 2, False), ("fb15k", 4, False), ("config4", 2, False), ("one_owner", 2, False),
+                                             ("fb15k", 2, True), ("fb15k", 4, True)])
+def test_sharded_real_kernels_match_c_port(name, world, peer):
+    """peer=True: the peer-mapped experiment -- the other ranks' shards mapped by CUDA IPC and read
+    in place by the gradient kernel, two stream-ordered cross-rank barriers per step instead of the row all-to-all."""
     import torch.multiprocessing as mp
     from oracle import c_oracle as CO
     if not torch.cuda.is_available():
@@ -97,7 +100,7 @@ def test_sharded_real_kernels_match_c_port(name, world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, name)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, name, peer)) for r in range(world)]
     for p in procs:
         p.start()
     deadline = time.time() + 420
