@@ -340,7 +340,7 @@ static int64_t prep_chunk_steps(int64_t B, int64_t negs = 0) {
 // training workspace: [gidx 6B][gval RING x (6B x d)][prep chunk buffer 0][prep chunk buffer 1].
 // The gradient rows go to a RING of regions, one per step in turn: a region is written by the grad kernel
 // on one XCD and read by the apply kernel on another, and rewriting lines that still sit in another XCD's
-// L2 costs ~3.7 us per 13 MB (tools/xcd_locality_probe.hip: 9.1 vs 5.4 us); by the time a region comes
+// L2 costs ~3.7 us per 13 MB (tools/probes/xcd_locality_probe.hip: 9.1 vs 5.4 us); by the time a region comes
 // round again (normally 4 steps later, > the 32 MB of L2 in between) its lines have been evicted and the
 // stores take the fast path.
 static size_t grad_region_bytes(int64_t B, int32_t d) {

@@ -790,7 +790,7 @@ def test_config3_fifty_dependent_spectral_steps_vs_fp64_oracle(H):
     """BASELINE config 3 (FB15k-shaped, HolE d=200, B=4096): 50 dependent steps with the table held in the
     frequency domain.  HolE under the reference's hyper-parameters (lr 0.1 on the SUM gradient of 4,096 pairs) is
     a chaotic map: two runs of ANY fp32 implementation -- these kernels or the direct-correlation ones -- that
-    differ only in the order of their float atomics drift apart by ~1.15x per step (tools/race_probe.py:
+    differ only in the order of their float atomics drift apart by ~1.15x per step (tools/probes/race_probe.py:
     6e-8 after one step, 1e-5 after fifty; ComplEx stays at 6e-8).  So each step is checked against the fp64
     numpy.fft oracle started from THE DEVICE'S OWN table before that step: loss vector within 1e-5, table after
     the step within 5e-6; the free-running trajectories are compared over the first 10 steps."""

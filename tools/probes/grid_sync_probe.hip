@@ -1,6 +1,6 @@
 // Probe: cost of a cooperative grid barrier on gfx950 (decides whether a persistent multi-step
 // training kernel can beat two launches per step). Build: hipcc --offload-arch=gfx950 -O3 -o
-// gpurun_out/grid_sync_probe tools/grid_sync_probe.hip
+// gpurun_out/grid_sync_probe tools/probes/grid_sync_probe.hip
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
 #include <cstdio>

@@ -1,5 +1,5 @@
 // Probe: sustained rate of v_mfma_f32_32x32x2_f32 on gfx950 (prices the 1-vs-K sweep, ge_1vk.hip).
-// Build on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_rate_probe tools/mfma_rate_probe.hip
+// Build on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_rate_probe tools/probes/mfma_rate_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 using f32x16 = __attribute__((ext_vector_type(16))) float;

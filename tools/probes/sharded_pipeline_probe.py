@@ -1,5 +1,5 @@
 """Does building chunk c+1's exchange plan on a side stream hide it behind chunk c's steps?  One MI355X,
-world_size 1, config-4 workload.  Usage (GPU box): python tools/sharded_pipeline_probe.py [B] [S] [chunks]"""
+world_size 1, config-4 workload.  Usage (GPU box): python tools/probes/sharded_pipeline_probe.py [B] [S] [chunks]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,5 @@
 // Probe: issue rate of v_fmac_f32 vs v_pk_fma_f32 on gfx950 (prices the HolE correlation loops).
-// Build on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate_probe tools/valu_rate_probe.hip
+// Build on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate_probe tools/probes/valu_rate_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));
