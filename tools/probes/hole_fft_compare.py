@@ -2,7 +2,7 @@
 (ifft(conj(fft(h)) * fft(t))) evaluated with torch.fft (rocFFT) on the same GPU, same rows already gathered
 and clipped for the FFT path (i.e. the FFT path is given a head start: no gather, no clip, no fusion)."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from graphembeddings_amd import hole as H
 

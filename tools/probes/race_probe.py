@@ -1,7 +1,7 @@
 """Stress: the same 50-step ge_train_steps call repeated from the same state; reports, per repeat, the first
 step whose loss vector deviates from repeat 0 by more than 1e-4 (hot rows use float atomics: ~1e-7 is normal)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from graphembeddings_amd import data as D, hole as H
 model = sys.argv[1] if len(sys.argv) > 1 else "hole"

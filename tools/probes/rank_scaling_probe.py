@@ -1,6 +1,6 @@
 """Time of the fused rank sweep vs embedding_dim (same 59,071 x 14,951 problem): per-tile fixed cost vs per-k cost."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from graphembeddings_amd import _lib
 if os.environ.get("GE_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["GE_LIB"])

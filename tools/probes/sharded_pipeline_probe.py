@@ -1,7 +1,7 @@
 """Does building chunk c+1's exchange plan on a side stream hide it behind chunk c's steps?  One MI355X,
 world_size 1, config-4 workload.  Usage (GPU box): python tools/probes/sharded_pipeline_probe.py [B] [S] [chunks]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from graphembeddings_amd import data as D, hole as H, sharded as S
 

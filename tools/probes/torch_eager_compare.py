@@ -2,7 +2,7 @@
 complex product, sigmoid, hinge, autograd, index_add_) on the same GPU, against ge_train_steps.
 Shows what the hand-written path buys over an eager framework translation; also a parity check of the loss."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from graphembeddings_amd import hole as H, data as D
 
