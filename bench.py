@@ -49,6 +49,9 @@ def parse():
                     help="N>1: which triples a rank trains -- those whose head row it owns (default), or a random share")
     ap.add_argument("--plan-group", action="store_true",
                     help="N>1: run the exchange planner's collectives on a second communicator (untested on hardware)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1, opt-in: fetch the rows of step s+1 that no rank touches in step s on a communication stream while "
+                         "step s computes (bitwise the serial schedule's result; not yet run on RCCL)")
     ap.add_argument("--peer-mapped", action="store_true",
                     help="N>1 EXPERIMENT: map the other ranks' shards by IPC and read their rows in place instead of the row "
                          "all-to-all (two cross-rank barriers per step); rehearsed on one device only, needs peer access on hardware")

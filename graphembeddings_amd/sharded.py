@@ -112,6 +112,14 @@ class HipKernels:
         return self.h.hole_from_spectral(shard)
 
 
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def shard_rows(table: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     """This rank's rows of a full table under owner(id) = id % world, local = id // world."""
     return table[rank::world].contiguous()
@@ -152,9 +160,39 @@ class ChunkPlan:
     req_all: torch.Tensor = None   # local row indices peers asked of me, ordered (step, peer)
     req_start: list = None
     owner: object = None           # backend-private owner-side plan (None at world size 1)
+    pre: FetchSplit = None         # overlapped schedule only
     ready: object = None           # event recorded on the side stream when the plan was built there
     unique_rows: int = 0
     remote_rows: int = 0
+
+
+@dataclass
+class FetchSplit:
+    """The overlapped schedule's split of every step's fetch (ShardedTrainer(overlap=True)): EARLY rows are those no
+    rank touches in the previous step (not an own row referenced there, not requested there), so their owner can
+    gather and send them while that step still computes; LATE rows wait for its updates.  Requester side: the staging
+    positions u of each kind; owner side: the request lists of each kind; split sizes per (step, peer)."""
+    sc_e: list
+    sc_l: list
+    rc_e: list
+    rc_l: list
+    idx_early: torch.Tensor        # int64, step-major: staging positions filled by the early all-to-all
+    idx_late: torch.Tensor
+    ie_start: list                 # [S+1] host offsets into idx_early / idx_late
+    il_start: list
+    req_early: torch.Tensor        # int32, (step, peer) order: rows gathered for the early all-to-all
+    req_late: torch.Tensor
+    re_start: list
+    rl_start: list
+    staged: dict = None            # step -> staging buffer that the early all-to-all of that step filled
+    done: dict = None              # step -> event recorded behind it on the communication stream
+
+
+def _segment_sums(flags: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    """Sum of `flags` over consecutive segments whose lengths are `lengths` (any shape, row-major)."""
+    c = torch.cat([torch.zeros(1, dtype=torch.int64, device=flags.device), torch.cumsum(flags.to(torch.int64), 0)])
+    ends = torch.cumsum(lengths.reshape(-1), 0)
+    return (c[ends] - c[ends - lengths.reshape(-1)]).view(lengths.shape)
 
 
 @dataclass
@@ -166,14 +204,21 @@ class StepStats:
 
 class ShardedTrainer:
     def __init__(self, shard: torch.Tensor, n_rows: int, type_tables, *, margin=0.2, model="complex",
-                 max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None, plan_group=None, peer_mapped=False):
+                 max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None, plan_group=None, peer_mapped=False,
+                 overlap=False):
         """peer_mapped (EXPERIMENT, one node, world <= 8, HipKernels): every rank maps the other ranks' shards into
         its address space (CUDA IPC handles exchanged once) and the gradient kernel reads the other owners' rows IN
         PLACE over the fabric: no gather, no row all-to-all, no staging buffer.  What it costs instead: two
         stream-ordered cross-rank barriers per step (nobody may update rows another rank is still reading; nobody may
         read rows whose owner has not finished the previous step's updates).  Gradient sums still go back by
         all-to-all.  Rehearsed with the ranks sharing one device; on real peers it additionally needs peer access
-        between the devices to be enabled, which this code does not do: do not enable it on hardware unverified."""
+        between the devices to be enabled, which this code does not do: do not enable it on hardware unverified.
+
+        overlap (opt-in, not yet run on RCCL): the rows of step s+1 that NO rank touches in step s -- the plan knows
+        them -- are gathered and sent on a communication stream while step s computes; only the remainder is fetched
+        in front of step s+1.  Same arithmetic, bitwise the same table as the serial schedule
+        (tests/test_gpu_sharded.py); one more flag exchange and one more size read-back per chunk.  All collectives
+        stay on ONE communicator and are issued in the same host order on every rank."""
         self.shard = shard
         self.N = int(n_rows)
         self.d = int(shard.shape[1])
@@ -203,6 +248,8 @@ class ShardedTrainer:
         # is training (the host blocks in the plan's size read-back until that chunk is done).
         self.plan_group = plan_group if plan_group is not None else group
         self.peer_mapped = bool(peer_mapped) and self.world > 1
+        self.overlap = bool(overlap) and self.world > 1 and not self.peer_mapped
+        self._comm = torch.cuda.Stream(device=shard.device) if (self.overlap and shard.is_cuda) else None
         if self.peer_mapped:
             self._map_peer_shards()
         self._side = torch.cuda.Stream(device=shard.device) if shard.is_cuda else None
@@ -265,17 +312,78 @@ class ShardedTrainer:
         mask = torch.arange(cap, device=dev).view(1, -1) < U.to(dev).view(-1, 1)
         flat = rp.req_row[mask]
         send_ids = torch.empty_like(flat)
+        rg = _regroup(n, ask) if n else None                            # flat position -> position in send order
         if n:
-            send_ids[_regroup(n, ask)] = flat
+            send_ids[rg] = flat
         recv_ids = self._a2a(send_ids, sc.sum(0).tolist(), rc.sum(0).tolist(), group=self.plan_group)
         n_req = int(recv_ids.numel())
         req_all = torch.empty_like(recv_ids)                            # received (peer, step) -> needed (step, peer)
+        rc_dev = rc.to(dev)
+        rmap = _regroup(n_req, rc_dev.t().contiguous()) if n_req else None   # receive position -> position in req_all
         if n_req:
-            req_all[_regroup(n_req, rc.to(dev).t().contiguous())] = recv_ids
+            req_all[rmap] = recv_ids
         req_start = [0] + torch.cumsum(rc.sum(1), 0).tolist()
         owner = self.k.plan_owner(req_all, req_start, int(self.shard.shape[0]))
+        pre = self._split_fetch(pos, neg, ask, sc, rc, rc_dev, rg, rmap, req_all, n, n_req) if self.overlap else None
         return ChunkPlan(S=S, B=B, sc=sc.tolist(), rc=rc.tolist(), req=rp, req_all=req_all, req_start=req_start,
-                         owner=owner, unique_rows=own + n, remote_rows=n)
+                         owner=owner, pre=pre, unique_rows=own + n, remote_rows=n)
+
+    def _split_fetch(self, pos, neg, ask, sc, rc, rc_dev, rg, rmap, req_all, n, n_req) -> "FetchSplit":
+        """Early / late split of every step's fetch (see FetchSplit).  Owner side: which requested rows of step s no
+        rank touches in step s-1 (step 0 of a chunk: none -- the previous chunk's last step is not looked at); the flags
+        travel back to the requesters by one all-to-all of bytes; one host read-back for the split sizes."""
+        G, dev, S = self.world, pos.device, int(pos.shape[0])
+        rows_local = int(self.shard.shape[0])
+        touched = torch.zeros(S * rows_local, dtype=torch.bool, device=dev)
+        ids = torch.cat([pos, neg], 1).reshape(S, -1).to(torch.int64)
+        mine = (ids >= 0) & (ids < self.N) & (ids % G == self.rank)      # every own row a step references may change in it
+        base = torch.arange(S, device=dev).view(S, 1) * rows_local
+        touched[(base + ids // G)[mine]] = True
+        req_step = torch.repeat_interleave(torch.arange(S, device=dev), rc_dev.sum(1), output_size=n_req)
+        req64 = req_all.to(torch.int64)
+        touched[req_step * rows_local + req64] = True                   # ... and every row somebody fetches (its sum comes back)
+        early_req = torch.zeros(n_req, dtype=torch.bool, device=dev)
+        later = req_step >= 1
+        early_req[later] = ~touched[(req_step[later] - 1) * rows_local + req64[later]]
+        # flags back to the requesters, in the order their id lists arrived in; there back into staging order
+        flags_send = early_req[rmap].to(torch.uint8) if n_req else torch.empty(0, dtype=torch.uint8, device=dev)
+        flags_recv = self._a2a(flags_send, rc.sum(0).tolist(), sc.sum(0).tolist(), group=self.plan_group)
+        flags = flags_recv[rg].bool() if n else torch.empty(0, dtype=torch.bool, device=dev)
+        U_dev = ask.sum(1)
+        step_of = torch.repeat_interleave(torch.arange(S, device=dev), U_dev, output_size=n)
+        u_of = torch.arange(n, device=dev) - (torch.cumsum(U_dev, 0) - U_dev)[step_of]
+        host = torch.stack([_segment_sums(flags, ask), _segment_sums(early_req, rc_dev)]).cpu()   # the split sizes
+        sc_e, rc_e = host[0], host[1]
+        sc_l, rc_l = sc - sc_e, rc - rc_e
+        starts = lambda m: [0] + torch.cumsum(m.sum(1), 0).tolist()
+        return FetchSplit(sc_e=sc_e.tolist(), sc_l=sc_l.tolist(), rc_e=rc_e.tolist(), rc_l=rc_l.tolist(),
+                          idx_early=u_of[flags], idx_late=u_of[~flags], ie_start=starts(sc_e), il_start=starts(sc_l),
+                          req_early=req_all[early_req], req_late=req_all[~early_req], re_start=starts(rc_e),
+                          rl_start=starts(rc_l), staged={}, done={})
+
+    def _prefetch(self, plan: "ChunkPlan", s: int) -> None:
+        """The early rows of step s: gather at the owners, all-to-all, placed at their staging positions -- on the
+        communication stream, behind everything enqueued so far (the previous step's updates, the plan), beside
+        whatever the main stream does next (the current step's kernels, which touch none of these rows)."""
+        pre = plan.pre
+        main = torch.cuda.current_stream(self.shard.device) if self._comm is not None else None
+        if main is not None:
+            here = torch.cuda.Event()
+            here.record(main)
+            self._comm.wait_event(here)
+        ctx = torch.cuda.stream(self._comm) if self._comm is not None else _NullContext()
+        with ctx:
+            rows = self.k.gather_rows(self.shard, pre.req_early[pre.re_start[s]:pre.re_start[s + 1]])
+            recv = self._a2a(rows, pre.rc_e[s], pre.sc_e[s])
+            staged = torch.empty(int(sum(plan.sc[s])), self.d, dtype=self.shard.dtype, device=self.shard.device)
+            if recv.shape[0]:
+                staged.index_copy_(0, pre.idx_early[pre.ie_start[s]:pre.ie_start[s + 1]], recv)
+            done = None
+            if self._comm is not None:
+                done = torch.cuda.Event()
+                done.record(self._comm)
+                staged.record_stream(main)
+        pre.staged[s], pre.done[s] = staged, done
 
     def step_planned(self, plan: "ChunkPlan", s: int, lr: float) -> torch.Tensor:
         """Step s of a planned chunk: fetch the other owners' rows (all-to-all), fused score/hinge/grad on the
@@ -287,6 +395,21 @@ class ShardedTrainer:
             if self.peer_mapped:
                 self._rank_barrier()                                    # every owner has finished the previous step's updates
                 gsum = torch.zeros(int(sum(sc)), self.d, dtype=self.shard.dtype, device=self.shard.device)
+            elif plan.pre is not None:                                  # overlapped schedule: this step's early rows are
+                pre = plan.pre                                          # already on their way (or there); fetch the rest
+                staged = pre.staged.pop(s, None)
+                if staged is None:
+                    staged = torch.empty(int(sum(sc)), self.d, dtype=self.shard.dtype, device=self.shard.device)
+                rows_out = self.k.gather_rows(self.shard, pre.req_late[pre.rl_start[s]:pre.rl_start[s + 1]])
+                recv = self._a2a(rows_out, pre.rc_l[s], pre.sc_l[s])
+                if recv.shape[0]:
+                    staged.index_copy_(0, pre.idx_late[pre.il_start[s]:pre.il_start[s + 1]], recv)
+                if s + 1 < plan.S:
+                    self._prefetch(plan, s + 1)                         # next step's early rows, beside this step's kernels
+                done = pre.done.pop(s, None)
+                if done is not None:
+                    torch.cuda.current_stream(self.shard.device).wait_event(done)
+                gsum = torch.zeros_like(staged)
             else:
                 req = plan.req_all[plan.req_start[s]:plan.req_start[s + 1]]
                 rows_out = self.k.gather_rows(self.shard, req)          # owners gather ...
@@ -341,6 +464,13 @@ class ShardedTrainer:
         tensors = list(self.k.plan_tensors(plan.req, plan.owner)) if hasattr(self.k, "plan_tensors") else []
         if plan.req_all is not None:
             tensors.append(plan.req_all)
+        if plan.pre is not None:
+            split = [plan.pre.idx_early, plan.pre.idx_late, plan.pre.req_early, plan.pre.req_late]
+            tensors += split
+            if self._comm is not None:
+                for t in split:
+                    if t.is_cuda:
+                        t.record_stream(self._comm)
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(cur)

@@ -132,3 +132,87 @@ def test_sharded_real_kernels_match_c_port(name, world, peer):
         assert np.abs(got_loss[s] - loss[:B]).max() < 1e-5
     assert np.abs(got_table - ref).max() < 2e-5
     assert remote > 0                                                     # rows really crossed ranks
+
+
+def _overlap_worker(rank, world, port, q):
+    import torch.distributed as dist
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            from graphembeddings_amd import hole as H
+            from graphembeddings_amd import sharded as S
+            torch.cuda.set_device(0)
+            rng = np.random.default_rng(3)
+            N, d, B, steps = 60000, 200, 2048, 6
+            # uniform ids, every triple its own pseudo-relation row: no row collects more than 16 slots in a step, so no
+            # float atomics anywhere and both schedules must give the same bits
+            tri = np.stack([rng.integers(0, N, (steps, world * B)), rng.integers(0, N, (steps, world * B)),
+                            rng.integers(0, N, (steps, world * B))], 2).astype(np.int32)
+            table = (rng.standard_normal((N, d)) * 0.05).astype(np.float32)
+            tt = H.TypeTables.from_host(np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32), padded_size=0)
+            mine = torch.as_tensor(np.ascontiguousarray(tri[:, rank * B:(rank + 1) * B])).cuda()
+            outs, early = [], 0
+            for overlap in (False, True):
+                shard = torch.as_tensor(np.ascontiguousarray(table[rank::world])).cuda()
+                tr = S.ShardedTrainer(shard, N, tt, margin=0.2, seed=21, overlap=overlap)
+                plan = tr.plan_chunk(mine, tr.sample_negatives(mine).to(torch.int32))
+                if overlap:
+                    early = sum(sum(r) for r in plan.pre.sc_e)
+                losses = torch.stack([tr.step_planned(plan, s, 0.1) for s in range(steps)])
+                outs.append((tr.gather_full_table(), losses))
+            torch.cuda.synchronize()
+            same = bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]))
+            if rank == 0:
+                q.put(("ok", same, early, outs[1][0].cpu().numpy(), tri, table))
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+    except Exception:
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def test_overlapped_schedule_is_bitwise_the_serial_one():
+    """ShardedTrainer(overlap=True) -- next step's untouched rows fetched on a communication stream beside the current
+    step's kernels -- at world 2 with the real kernels: the same bits as the serial schedule (tables and losses), early
+    rows really existed, and the result is the C port's."""
+    import torch.multiprocessing as mp
+    from oracle import c_oracle as CO
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    deadline, msg = time.time() + 420, None
+    while time.time() < deadline:
+        if not q.empty():
+            msg = q.get()
+            break
+        if not any(p.is_alive() for p in procs):
+            break
+        time.sleep(0.2)
+    if msg is None and not q.empty():
+        msg = q.get()
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
+    assert msg[0] == "ok", f"rank {msg[1]} failed:\n{msg[2]}"
+    _, same, early, got, tri, table = msg
+    assert same, "overlapped and serial schedules differ"
+    assert early > 0
+    N = table.shape[0]
+    id_to_type, offsets, ids = np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32)
+    ref = table.copy()
+    B = tri.shape[1] // world
+    for s in range(tri.shape[0]):
+        pos = tri[s]
+        neg = np.concatenate([CO.corrupt_batch(pos[r * B:(r + 1) * B], id_to_type, offsets, ids, 21, s * world + r, 0, 0)
+                              for r in range(world)], 0)
+        CO.hinge_step(ref, pos, neg, 0.2, 0.1, threads=16)
+    assert np.abs(got - ref).max() < 2e-5

@@ -107,6 +107,35 @@ def _problem(dtype=np.float64):
     return table.astype(dtype), id_to_type, offsets, type_ids, pos
 
 
+def _worker_overlap(rank, world, port, q):
+    """Three steps as ONE planned chunk with the overlapped schedule: the early rows of steps 1 and 2 are fetched before
+    the step in front of them has run (inline here: no streams on the CPU), the late ones behind it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphembeddings_amd import sharded as S
+        table, id_to_type, offsets, type_ids, pos = _problem()
+        tt = SimpleNamespace(id_to_type=id_to_type, type_offsets=offsets, type_ids=type_ids, padded_size=32)
+        full = torch.as_tensor(table)
+        tr = S.ShardedTrainer(S.shard_rows(full, rank, world), full.shape[0], tt, margin=0.2, seed=9,
+                              kernels=OracleKernels(), overlap=True)
+        B = len(pos)
+        mine = torch.as_tensor(pos[rank * B // world:(rank + 1) * B // world])
+        chunk = torch.stack([mine, mine, mine], 0).to(torch.int32)
+        plan = tr.plan_chunk(chunk, tr.sample_negatives(chunk).to(torch.int32))
+        early = sum(sum(r) for r in plan.pre.sc_e)
+        losses = [tr.step_planned(plan, s, 0.05) for s in range(3)]
+        out = tr.gather_full_table()
+        stats = torch.tensor([early, sum(sum(r) for r in plan.sc)])
+        dist.all_reduce(stats)
+        if rank == 0:
+            q.put((out.numpy(), [l.numpy() for l in losses], float(stats[0]), float(stats[1])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -176,6 +205,45 @@ def test_sharded_step_equals_single_process_result(world):
         assert np.abs(got_losses[step] - loss[:B // world]).max() < 1e-6   # rank 0 holds the first slice
     assert np.abs(got_table - ref).max() < 1e-12
     assert uniq > 0 and np.isfinite(mean)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_schedule_equals_single_process_result(world):
+    """ShardedTrainer(overlap=True): rows of step s+1 that no rank touches in step s are fetched BEFORE step s runs.
+    Same result as the single-process reference, and some rows really were early."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    deadline, msg = time.time() + 240, None
+    while time.time() < deadline:
+        if not q.empty():
+            msg = q.get()
+            break
+        if not any(p.is_alive() for p in procs):
+            break
+        time.sleep(0.1)
+    if msg is None and not q.empty():
+        msg = q.get()
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
+    assert all(p.exitcode == 0 for p in procs)
+    got_table, got_losses, early, total = msg
+    table, id_to_type, offsets, type_ids, pos = _problem()
+    B = len(pos)
+    ref = table.copy()
+    for step in range(3):
+        negs = [O.corrupt_batch(pos[r * B // world:(r + 1) * B // world], id_to_type, offsets, type_ids, 9,
+                                step * world + r, 32, 0) for r in range(world)]
+        ref, loss = O.sgd_step(ref, pos, np.concatenate(negs, 0), lr=0.05, margin=0.2)
+        assert np.abs(got_losses[step] - loss[:B // world]).max() < 1e-6
+    assert np.abs(got_table - ref).max() < 1e-12
+    assert 0 < early < total          # steps 1 and 2 had early rows; step 0 (and every touched row) had none
 
 
 def test_single_rank_degenerates_to_plain_step():
