@@ -200,6 +200,7 @@ class StepStats:
     unique_rows: int = 0
     remote_rows: int = 0
     bytes_sent: int = 0
+    early_rows: int = 0        # overlapped schedule: fetched rows per step that travelled beside the previous step
 
 
 class ShardedTrainer:
@@ -507,7 +508,8 @@ class ShardedTrainer:
             done = plan
             plan = self._plan_ahead(chunks[c + 1], self.global_step, ready) if c + 1 < len(chunks) else None
             self.stats = StepStats(unique_rows=done.unique_rows // done.S, remote_rows=done.remote_rows // done.S,
-                                   bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)))
+                                   bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)),
+                                   early_rows=(sum(sum(r) for r in done.pre.sc_e) // done.S) if done.pre is not None else 0)
         if lookahead is not None:
             self._pending = (lookahead, self.global_step, self._plan_ahead(lookahead, self.global_step, ready))
         return torch.stack(losses, 0) if losses else None

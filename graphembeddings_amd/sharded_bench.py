@@ -155,7 +155,8 @@ def run(args, emit=True):
                        "batch_per_gpu": B, "embedding_dim": d, "table_rows": N,
                        "table_mb_per_gpu": round(rows * d * 4 / 1e6, 1), "parallelism": f"row-shard x{world}",
                        "per_gpu_value": 2.0 * B * K / el, "unique_rows_per_step": stats.unique_rows,
-                       "remote_rows_per_step": stats.remote_rows, "a2a_bytes_per_step_per_gpu": stats.bytes_sent,
+                       "remote_rows_per_step": stats.remote_rows, "early_rows_per_step": stats.early_rows,
+                       "a2a_bytes_per_step_per_gpu": stats.bytes_sent,
                        "final_mean_hinge": round(mean_loss, 6)},
             "roofline": {"bound": "hbm", "kernel": "complex_hinge_grad_kernel (shard rows in place + staged rows)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
