@@ -23,6 +23,12 @@ int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                      float* scores_out, int spec, hipStream_t st);
 
+// ge_rank_f16.hip: the split-precision sweep (embedding_dim % 8 == 0 in 56 ... 208, max_norm <= 8), ranks or scores
+int sweep_f16_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                     const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
+                     const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
+                     float* scores_out, int spec, int scores_only, int sweep_flags, hipStream_t st);
+
 // ge_complex_score_1vK on the pipelined sweep (same GE_ENOTSUP convention)
 int score_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* cand,
                       int64_t K, float max_norm, int apply_sigmoid, int cand_is_head, float* out, hipStream_t st);

@@ -24,6 +24,7 @@
 //   * model: ComplEx, or HolE on a table held in the frequency domain (same GEMM; Hermitian weights go into Q,
 //     the candidate norm is Parseval-weighted).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "ge_rank_dev.h"
@@ -839,6 +840,11 @@ int sweep_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* h
                       const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                       const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                       float* scores_out, int spec, int scores_only, int sweep_flags, hipStream_t st) {
+  if (!getenv("GE_RANK_F16_OLD")) {
+    const int rc = sweep_f16_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
+                                    skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, st);
+    if (rc != GE_ENOTSUP) return rc;
+  }
 #define GE_PIPE(CW)                                                                                                  \
   return pipe_launch_cw<CW>(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt, \
                             skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, st)
