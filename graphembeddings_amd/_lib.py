@@ -48,6 +48,9 @@ SYMBOLS = {
     "ge_rank_max_dim": (C.c_int, []),
     "ge_complex_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "ge_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
+    "ge_rank_planes_bytes": (_i64, [_i64, _i32, _i64]),
+    "ge_rank_planes": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
+    "ge_rank_1vK_planes": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ge_train_workspace_bytes": (_sz, [_i64, _i32]),
     "ge_train_pipeline_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ge_train_pipeline_reset": (C.c_int, [_p]),

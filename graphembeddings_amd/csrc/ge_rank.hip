@@ -355,14 +355,14 @@ int rank_max_dim() { return 232; }   // Q (128 x (d+1) floats) + two candidate c
 int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                             const int32_t* true_id, const int32_t* cand, int64_t K, float max_norm, int cand_is_head,
                             const int32_t* known_off, const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt,
-                            float* true_loss, float* scores_out, int spec, hipStream_t st) {
+                            float* true_loss, float* scores_out, int spec, const void* planes_ws, hipStream_t st) {
   if (d <= 0 || (d & 7)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;   // 16-byte candidate loads, 8-float tail
   if (d > rank_max_dim()) return GE_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
   if (B == 0 || K == 0) return 0;
   {  // embedding_dim a multiple of 40, 32 or 24: the software-pipelined kernel (ge_rank_pipe.hip)
     const int rc = rank_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,
-                                    raw_cnt, skip_cnt, true_loss, scores_out, spec, st);
+                                    raw_cnt, skip_cnt, true_loss, scores_out, spec, planes_ws, st);
     if (rc != GE_ENOTSUP) return rc;
   }
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;

@@ -1,28 +1,36 @@
-// ge_rank_f16.hip -- the split-precision link-prediction sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip)
-// with TWO waves per SIMD.
+// ge_rank_f16.hip -- the split-precision link-prediction sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip):
+// f16 MFMAs on pre-split candidate planes, two waves per SIMD in alternating phases.
 //
-// tools/probes/mfma_gap_probe.hip (profiles/r03_mfma_gap_probe.txt) says why: with one wave per SIMD the shadow of a
-// v_mfma_f32_32x32x16_f16 hides four or five INDEPENDENT VALU instructions and next to nothing of the rank epilogue's
-// compare -> scalar -> v_addc / v_writelane chains (12 such instructions cost 58-68 cycles wherever they are put,
-// between the MFMAs or behind them), so cutting the epilogue into the gaps of the next tile gained nothing (measured).
-// A second wave on the SIMD runs its MFMAs under the first one's epilogue and staging: the same instruction mix goes
-// through 1.45-1.5 x faster.  So: 512 threads per workgroup, eight waves of 64 x 32 scores each on a 128 x 128 tile,
-// <= 256 registers a wave.
+// Why this shape (tools/probes/mfma_gap_probe.hip -> profiles/r03_mfma_gap_probe.txt, tools/probes/rank_phase_probe.py):
+//   * with one wave per SIMD the shadow of a v_mfma_f32_32x32x16_f16 hides four or five INDEPENDENT VALU instructions
+//     and next to nothing of the rank epilogue's compare -> scalar -> v_addc / v_writelane chains: cutting the epilogue
+//     into the gaps of the next tile's MFMAs gained nothing (measured);
+//   * eight waves that all run the MFMA loop and then all run the epilogue (one barrier domain) gain 9 %: the second
+//     wave of a SIMD must be in the OTHER phase.  So the workgroup is two groups of four waves (one per SIMD each).
+//     Each group sweeps its own 128 x 64 tiles -- staging buffers and bitmaps of its own -- and the groups run the same
+//     cycle of intervals half a cycle apart: while one issues MFMAs the other runs its epilogue, counts and stores.
+//     s_barrier counts all eight waves, so both groups execute the same number of barriers per cycle (the epilogue
+//     is cut into four pieces with a barrier behind each, a padding barrier makes the count even);
+//   * splitting a candidate row into fp16 planes (norm, clip scale, 2 x cvt_pkrtz per pair) was half of the sweep's
+//     VALU work and was repeated for every block of 128 test rows: it is now a pre-pass (rank_planes_launch) whose
+//     output -- `planes`, laid out per 64-candidate tile and 32-column chunk -- the sweep only copies into LDS.
 //
 // x * 2^8 = hi + mid with two fp16 values (round toward zero, so mid has hi's sign) is exact to 22 bits, and
 //     q . t  =  2^-16 (qh.th + qh.tm + qm.th)  +  O(2^-22) per product
 // accumulated in fp32: three f16 MFMAs per 16-wide k block.  Q (pre-multiplied by the rows' clip scales) sits in LDS
-// as two fp16 planes for the whole row block; a candidate row (held whole in registers a tile ahead, so its clip scale
-// is known before anything is stored) is split chunk by chunk (32 columns) as it is stored to LDS.
-// The kernel is compiled per number of k blocks (embedding_dim 64 ... 208, any multiple of 8); embedding_dim itself is
-// a run-time value (the clamp of the row's last requests, the zero fill behind the row).
-// Epilogue: as ge_rank_pipe.hip -- raw scores against a bracket of the true candidate's raw score, bits into a
-// row-major bitmap by v_writelane, the exact fp32 comparison only for scores inside the bracket.
+// as two fp16 planes for the whole row block.  The kernel is compiled per number of k blocks (embedding_dim 56 ... 208,
+// any multiple of 8); embedding_dim itself is a run-time value.
+// Epilogue: raw scores against a bracket of the true candidate's raw score, bits into a row-major bitmap by
+// v_writelane, the exact fp32 comparison (id tie-break) only for scores inside the bracket -- the outcome equals
+// comparing the sigmoids everywhere.
 #include <algorithm>
 #include <type_traits>
 
 #include "ge_rank_dev.h"
 
+#ifndef GE_RANK_X
+#define GE_RANK_X 0      // diagnostic builds: 1 no bracket sequences, 2 no chunk loads / stores in the MFMA loop, 4 no MFMAs
+#endif
 #ifndef GE_PIPE_GRID_M
 #define GE_PIPE_GRID_M 2   // workgroups per CU (each CU holds one at a time): equal shares, two rounds
 #endif
@@ -32,12 +40,14 @@ namespace {
 
 #ifdef GE_RANK_STAMPS   // diagnostic build only (tools/probes/rank_phase_probe.py): cycles per phase, summed over waves
 __device__ unsigned long long g_rank_stamps[16];
-#define GE_STAMP(i, t_prev) do { const long long now_ = __builtin_readcyclecounter(); st_[i] += now_ - (t_prev); (t_prev) = now_; } while (0)
+#define GE_STAMP(i) do { const long long now_ = __builtin_readcyclecounter(); st_[i] += now_ - tp_; tp_ = now_; } while (0)
 #else
-#define GE_STAMP(i, t_prev) do { } while (0)
+#define GE_STAMP(i) do { } while (0)
 #endif
 
-constexpr int kBlk = 512;               // 8 waves: wm = w >> 2 (64 rows), wn = w & 3 (32 candidates)
+constexpr int kBlk = 512;               // two groups of four waves; in a group wm = wg >> 1 (64 rows), wn = wg & 1 (32 candidates)
+constexpr int kGrp = 256;
+constexpr int kCT = 64;                 // candidates per group tile
 
 template <int I0, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -55,32 +65,39 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int KKB>
 struct HCfg {
   static constexpr int kKB = KKB;                   // k blocks of 16 (the last zero padded behind embedding_dim)
-  static constexpr int kChunks = (KKB + 1) / 2;     // staged chunks of two k blocks = register slots of 32 reals
+  static constexpr int kChunks = (KKB + 1) / 2;     // staged chunks of two k blocks (32 columns)
   static constexpr int kSA = 16 * KKB + 8;          // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
-  static_assert(KKB >= 4 && KKB <= 13, "embedding_dim 64 ... 208 (LDS: Q planes + two chunk buffers)");
+  // barriers per tile cycle of a group: kChunks - 1 in the MFMA loop, 4 behind the epilogue pieces, 1 behind the
+  // count / next tile's first chunk; + 1 of padding when that is odd (the groups run half a cycle apart)
+  static constexpr int kCycle = ((kChunks + 4) + 1) / 2 * 2;
+  static constexpr int kPad = kCycle - (kChunks + 4);
+  static_assert(KKB >= 4 && KKB <= 13, "embedding_dim 56 ... 208 (LDS: Q planes + two chunk buffers per group)");
 };
-constexpr int kSB = 32 + 8;             // halves per candidate chunk row
+constexpr int kSB = 32 + 8;             // halves per candidate chunk row in LDS
 constexpr float kQScale = 256.f;        // both operands: |q|, |t * clip| <= max_norm^2 resp. max_norm sqrt(d/2)
+constexpr int kChunkHalves = 2 * kCT * 32;   // one chunk of a 64-candidate tile in `planes`: [plane][row][32 columns]
 
 struct HLds {
   _Float16* Ah;    // [kRB][kSA] high halves of Q * 2^8 ...
   _Float16* Am;    //   ... and the remainders (Q * 2^8 = Ah + Am to 22 bits)
-  _Float16* Bp;    // [2 buffers][2 planes][kRB][kSB] candidate chunk * clip * 2^8, high halves | remainders
+  _Float16* Bp;    // this group's [2 buffers][2 planes][kCT][kSB] candidate chunk: high halves | remainders
   float* sA;       // [kRB] 2^-16 (NaN: bad id / beyond B)
   float* eT;       // [kRB] loss of the true candidate
   float2* lohi;    // [kRB] raw-score bracket of the true candidate
-  unsigned* bm;    // [kRB][4] `pops before` bits of the current tile
+  unsigned* bm;    // this group's [kRB][2] `pops before` bits of its current tile
   int* skip;       // [kRB] known-true candidates ranked before the target
   int* tI;         // [kRB] entity id of the true candidate (-1 beyond B)
+  int* tP;         // [kRB] its position among the candidates (-1: not a candidate)
 };
 
 template <int KKB>
 constexpr size_t h_lds_bytes() {
-  return sizeof(_Float16) * ((size_t)2 * kRB * HCfg<KKB>::kSA + 2 * 2 * kRB * kSB) + sizeof(float) * 2 * kRB +
-         sizeof(float2) * kRB + sizeof(unsigned) * kRB * 4 + sizeof(int) * 2 * kRB;
+  return sizeof(_Float16) * ((size_t)2 * kRB * HCfg<KKB>::kSA + 2 * 2 * 2 * kCT * kSB) + sizeof(float) * 2 * kRB +
+         sizeof(float2) * kRB + sizeof(unsigned) * 2 * kRB * 2 + sizeof(int) * 3 * kRB;
 }
 
 struct HOps { h8 ah[2], am[2], bh, bm; };           // one k block of this wave's 64 x 32 block
+struct HL { h8 hi, mid; };                           // this thread's 16 + 16 bytes of a staged chunk
 
 __device__ __forceinline__ void h_split(float x0, float x1, h2& hi, h2& mid) {
   typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -90,15 +107,11 @@ __device__ __forceinline__ void h_split(float x0, float x1, h2& hi, h2& mid) {
   mid = __builtin_bit_cast(h2, m);
 }
 
-// v_writelane_b32 with a constant lane: lane `LANE` of m = the wave-uniform v
+// v_writelane_b32 with a constant lane: lane `LANE` of m = the wave-uniform v (v must not come straight out of a
+// VALU compare: see bracket_item)
 template <int LANE>
 __device__ __forceinline__ void set_lane(int& m, unsigned v) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(v), "n"(LANE));
-}
-// m = 2 * m + (this lane's bit of the wave mask): one v_addc_co_u32 with the mask as carry-in
-__device__ __forceinline__ void shift_in(unsigned& m, unsigned long long mask) {
-  unsigned long long carry_out;
-  asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(m), "=s"(carry_out) : "s"(mask));
 }
 
 // One score of the bracket epilogue, as ONE instruction sequence (the compiler's hazard recognizer does not look
@@ -119,121 +132,86 @@ __device__ __forceinline__ void bracket_item(float x, float2 br, int& M, unsigne
       : "vcc");
 }
 
-// A candidate row in flight: slot c = columns 32 c + 8 qt ... + 7 of the row (this thread's quarter of chunk c), and
-// the two real bins of a spectral row.  Requests are clamped into the row, never predicated.
-template <int KKB>
-struct HRow {
-  float4 r[HCfg<KKB>::kChunks][2];
-  float x_dc, x_ny;
-};
-
-template <int KKB>
-__device__ __forceinline__ void h_fetch_slot(const float* __restrict__ row, int d, int qt, int c, float4 (&r)[2]) {
-  const int col = min(c * 32 + qt * 8, d - 8);
-  r[0] = *reinterpret_cast<const float4*>(row + col);
-  r[1] = *reinterpret_cast<const float4*>(row + col + 4);
+// chunk c of a tile of `planes` -> registers; src = the thread's 16 bytes of the tile's chunk 0, high plane
+__device__ __forceinline__ void h_load(HL& L, const _Float16* __restrict__ src, int c) {
+  L.hi = *reinterpret_cast<const h8*>(src + c * kChunkHalves);
+  L.mid = *reinterpret_cast<const h8*>(src + c * kChunkHalves + kCT * 32);
+}
+__device__ __forceinline__ void h_write(const HLds& lds, const HL& L, int srow, int qt, int buf) {
+  *reinterpret_cast<h8*>(lds.Bp + ((buf * 2 + 0) * kCT + srow) * kSB + qt * 8) = L.hi;
+  *reinterpret_cast<h8*>(lds.Bp + ((buf * 2 + 1) * kCT + srow) * kSB + qt * 8) = L.mid;
 }
 
-// this thread's 8 reals of slot C, times `scale` (0 behind the row), split to the two planes of LDS buffer `buf`
-template <int KKB, int C>
-__device__ __forceinline__ void h_stash(const HLds& lds, int d, int srow, int qt, int buf, const float4 (&r)[2], float scale) {
-  constexpr bool may_end = C * 32 + 32 > 16 * (KKB - 1);          // the row may end inside this slot
-  float x[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
-  const bool in = !may_end || C * 32 + qt * 8 < d;                // (embedding_dim % 8 == 0: all eight or none)
-  h8 hi, mid;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h2 a, b;
-    h_split(in ? x[2 * i] * scale : 0.f, in ? x[2 * i + 1] * scale : 0.f, a, b);
-    hi[2 * i] = a.x; hi[2 * i + 1] = a.y; mid[2 * i] = b.x; mid[2 * i + 1] = b.y;
-  }
-  *reinterpret_cast<h8*>(lds.Bp + ((buf * 2 + 0) * kRB + srow) * kSB + qt * 8) = hi;
-  *reinterpret_cast<h8*>(lds.Bp + ((buf * 2 + 1) * kRB + srow) * kSB + qt * 8) = mid;
-}
-
-// piece i (0..5) of the operands of k block `kb`: ah0 ah1 am0 am1 bh bm
+// piece i (0..5) of the operands of k block `kb`, in the order the MFMAs of that k block first need them -- bh ah0 ah1
+// bm am0 am1 -- so that every piece is requested five or six MFMAs (>= 160 cycles) before its first use
 template <int KKB>
 __device__ __forceinline__ void h_ops_piece(HOps& o, const HLds& lds, int wm, int wn, int li, int lh, int kb, int i) {
   constexpr int kSA = HCfg<KKB>::kSA;
-  if (i < 4) {
-    const _Float16* ap = (i & 2 ? lds.Am : lds.Ah) + (wm * 64 + (i & 1) * 32 + li) * kSA + kb * 16 + lh * 8;
-    if (i & 2) o.am[i & 1] = *reinterpret_cast<const h8*>(ap); else o.ah[i & 1] = *reinterpret_cast<const h8*>(ap);
+  if (i == 0 || i == 3) {
+    const int buf = (kb >> 1) & 1, within = kb & 1, plane = i == 3;
+    const _Float16* bp = lds.Bp + ((buf * 2 + plane) * kCT + wn * 32 + li) * kSB + within * 16 + lh * 8;
+    if (plane) o.bm = *reinterpret_cast<const h8*>(bp); else o.bh = *reinterpret_cast<const h8*>(bp);
   } else {
-    const int buf = (kb >> 1) & 1, within = kb & 1;
-    const _Float16* bp = lds.Bp + ((buf * 2 + (i & 1)) * kRB + wn * 32 + li) * kSB + within * 16 + lh * 8;
-    if (i & 1) o.bm = *reinterpret_cast<const h8*>(bp); else o.bh = *reinterpret_cast<const h8*>(bp);
+    const int tm = (i == 2 || i == 5), mid = i >= 4;
+    const _Float16* ap = (mid ? lds.Am : lds.Ah) + (wm * 64 + tm * 32 + li) * kSA + kb * 16 + lh * 8;
+    if (mid) o.am[tm] = *reinterpret_cast<const h8*>(ap); else o.ah[tm] = *reinterpret_cast<const h8*>(ap);
   }
 }
 
-// One 128 x 128 tile.  R holds this tile's candidate row on entry and the NEXT tile's row (next_row) on exit: a slot
-// is refilled right after it has been stored to LDS, a whole tile ahead of its use.
+// Register slot schedule of the staged chunks.  Chunk c of a tile lives in L[c & 1] from its request to its store into
+// LDS buffer c & 1.  Slot j = -1 ... kChunks - 2 is the moment L[(j + 1) & 1] has just been stored (chunk j + 1; j = -1:
+// chunk 0, stored behind the previous tile's count): it is refilled at once with chunk j + 3 of the same tile or, past
+// the tile's end, with the next tile's chunk of that parity -- two chunks (24 MFMAs) ahead of its own store.
+template <int KKB, int J>
+__device__ __forceinline__ void h_refill(HL (&L)[2], const _Float16* __restrict__ cur, const _Float16* __restrict__ nxt) {
+  constexpr int i = J + 3;
+  if constexpr (i < HCfg<KKB>::kChunks) h_load(L[(J + 1) & 1], cur, i);
+  else h_load(L[(J + 1) & 1], nxt, (J + 1) & 1);
+}
+
+// The MFMA loop of one 128 x 64 tile: chunk 0 is in LDS buffer 0 (behind a barrier), chunk 1 in L[1], chunk 2 (or the
+// next tile's chunk 0) on its way into L[0].  kChunks - 1 barriers.  On exit L[0] / L[1] hold (or await) the NEXT
+// tile's chunks 0 / 1.
 template <int KKB>
-__device__ __forceinline__ void h_tile(const float* __restrict__ next_row, int d, bool bad, float max_norm, int spec,
-                                       const HLds& lds, HRow<KKB>& R, f32x16 (&acc)[2], long long (&st_)[8], long long& tp_) {
+__device__ __forceinline__ void h_mfma_loop(const HLds& lds, const _Float16* __restrict__ cur, const _Float16* __restrict__ nxt,
+                                            HL (&L)[2], f32x16 (&acc)[2], int srow, int qt, int wm, int wn, int li, int lh) {
   constexpr int kKB = KKB, kChunks = HCfg<KKB>::kChunks;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
-  const int srow = t >> 2, qt = t & 3;
-  const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[a][q] = 0.f;
-  // The whole row is in registers, so its clip scale is known BEFORE anything is stored: the planes hold
-  // t * clip(t) * 2^8 (|t clip| <= max_norm, or max_norm sqrt(d/2) for one bin of a spectral row: no fp16 overflow
-  // for max_norm <= 8 whatever the table holds) and the epilogue needs no column scale.
-  f2 ss2 = {0.f, 0.f};
-  static_for<0, kChunks>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    constexpr bool may_end = c * 32 + 32 > 16 * (KKB - 1);
-    const bool in = !may_end || c * 32 + qt * 8 < d;
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const f2 xy = in ? f2{R.r[c][v].x, R.r[c][v].y} : f2{0.f, 0.f}, zw = in ? f2{R.r[c][v].z, R.r[c][v].w} : f2{0.f, 0.f};
-      ss2 = __builtin_elementwise_fma(xy, xy, ss2);
-      ss2 = __builtin_elementwise_fma(zw, zw, ss2);
-    }
-  });
-  float ss = ss2.x + ss2.y;
-  ss += __shfl_xor(ss, 1, kWave);
-  ss += __shfl_xor(ss, 2, kWave);
-  // spectral HolE rows: |x|^2 = (2 sum - X_0^2 - X_k^2) / d; the two real bins sit at columns 0 and d/2
-  if (spec) ss = (2.f * ss - R.x_dc * R.x_dc - R.x_ny * R.x_ny) / (float)d;
-  float inv;
-  const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
-  h_stash<KKB, 0>(lds, d, srow, qt, 0, R.r[0], scale);
-  R.x_dc = next_row[0];
-  R.x_ny = next_row[d >> 1];
-  GE_STAMP(0, tp_);
-  __syncthreads();
-  GE_STAMP(1, tp_);
   HOps ops[2];
 #pragma unroll
   for (int i = 0; i < 6; ++i) h_ops_piece<KKB>(ops[0], lds, wm, wn, li, lh, 0, i);
   static_for<0, kKB>([&](auto kbc) {
     constexpr int kb = decltype(kbc)::value, qc = kb >> 1, within = kb & 1;
     constexpr bool last_of_chunk = within == 1 || kb == kKB - 1;
-    constexpr int nslot = qc + 1 < kChunks ? qc + 1 : 0;          // the slot stored / refilled beside chunk qc
-    if (last_of_chunk && qc + 1 < kChunks) __syncthreads();       // chunk qc+1 is in LDS; chunk qc-1's buffer is free
-    HOps& cur = ops[kb & 1];
-    HOps& nxt = ops[(kb + 1) & 1];
+    if constexpr (last_of_chunk && qc + 1 < kChunks) __syncthreads();   // chunk qc+1 is in LDS; chunk qc-1's buffer is free
+    HOps& cur_ops = ops[kb & 1];
+    HOps& nxt_ops = ops[(kb + 1) & 1];
     static_for<0, 6>([&](auto pc) {
       constexpr int p = decltype(pc)::value, ty = p >> 1, tm = p & 1;   // consecutive MFMAs hit different accumulators
-      const h8 a = ty == 2 ? cur.am[tm] : cur.ah[tm];
-      const h8 b = ty == 1 ? cur.bm : cur.bh;
-      acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm], 0, 0, 0);
+      const h8 a = ty == 2 ? cur_ops.am[tm] : cur_ops.ah[tm];
+      const h8 b = ty == 1 ? cur_ops.bm : cur_ops.bh;
+      if constexpr (!(GE_RANK_X & 4)) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm], 0, 0, 0);
+      else asm volatile("v_pk_add_f16 %0, %1, %2" : "+v"(acc[tm][p]) : "v"(a[0]), "v"(b[0]));   // (keeps the operand reads alive)
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kb + 1 < kKB) h_ops_piece<KKB>(nxt, lds, wm, wn, li, lh, kb + 1, p);
-      if constexpr (!last_of_chunk) {                             // first k block of a chunk: store chunk qc+1
-        if constexpr (p == 3 && qc + 1 < kChunks) h_stash<KKB, nslot>(lds, d, srow, qt, (qc + 1) & 1, R.r[nslot], scale);
-      } else if constexpr (p >= 4) {                              // last k block: refill the slot just stored
-        R.r[nslot][p - 4] = *reinterpret_cast<const float4*>(next_row + min(nslot * 32 + qt * 8, d - 8) + 4 * (p - 4));
+      if constexpr (kb + 1 < kKB) {
+        if constexpr ((GE_RANK_X & 16) || ((GE_RANK_X & 8) && p != 0 && p != 3)) {   // diagnostic: operands not re-read
+          if constexpr (p == 0) nxt_ops.bh = cur_ops.bh; else if constexpr (p == 3) nxt_ops.bm = cur_ops.bm;
+          else if constexpr (p == 1) nxt_ops.ah[0] = cur_ops.ah[0]; else if constexpr (p == 2) nxt_ops.ah[1] = cur_ops.ah[1];
+          else if constexpr (p == 4) nxt_ops.am[0] = cur_ops.am[0]; else nxt_ops.am[1] = cur_ops.am[1];
+        } else {
+          h_ops_piece<KKB>(nxt_ops, lds, wm, wn, li, lh, kb + 1, p);
+        }
+      }
+      if constexpr (within == 0 && qc + 1 < kChunks && !(GE_RANK_X & 2)) {   // first k block of a chunk: store chunk qc+1, refill its slot
+        if constexpr (p == 2) h_write(lds, L[(qc + 1) & 1], srow, qt, (qc + 1) & 1);
+        if constexpr (p == 3) h_refill<KKB, qc>(L, cur, nxt);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
   });
-  GE_STAMP(2, tp_);
-  __syncthreads();                              // the bitmask / bracket arrays of the epilogue are free again
-  GE_STAMP(3, tp_);
 }
 
 // MODE 0: ranks.  1: ranks, every loss computed exactly and stored too (tests).  2: no ranking at all -- the sweep
@@ -244,28 +222,46 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
     int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
-    float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags) {
+    float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags,
+    const int32_t* __restrict__ pos_of, const _Float16* __restrict__ planes) {
   constexpr bool SCORES = MODE == 1;
-  constexpr int kChunks = HCfg<KKB>::kChunks, kSA = HCfg<KKB>::kSA;
+  constexpr int kChunks = HCfg<KKB>::kChunks, kSA = HCfg<KKB>::kSA, kCycle = HCfg<KKB>::kCycle;
+  constexpr int64_t kTileHalves = (int64_t)kChunks * kChunkHalves;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = w >> 2, wg = w & 3, wm = wg >> 1, wn = wg & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tg = t & (kGrp - 1), srow = tg >> 2, qt = tg & 3;    // this group's staging: row of the 64-candidate tile, quarter
+  const int n_t64 = 2 * n_ct;                                    // tiles in `planes` (rows behind K: NaN)
   HLds lds;
   lds.Ah = reinterpret_cast<_Float16*>(smem);
   lds.Am = lds.Ah + kRB * kSA;
-  lds.Bp = lds.Am + kRB * kSA;
-  lds.sA = reinterpret_cast<float*>(lds.Bp + 2 * 2 * kRB * kSB);
+  _Float16* bp0 = lds.Am + kRB * kSA;
+  lds.Bp = bp0 + g * (2 * 2 * kCT * kSB);
+  lds.sA = reinterpret_cast<float*>(bp0 + 2 * 2 * 2 * kCT * kSB);
   lds.eT = lds.sA + kRB;
   lds.lohi = reinterpret_cast<float2*>(lds.eT + kRB);             // an even number of floats in: 8-byte aligned
-  lds.bm = reinterpret_cast<unsigned*>(lds.lohi + kRB);
-  lds.skip = reinterpret_cast<int*>(lds.bm + kRB * 4);
+  unsigned* bm0 = reinterpret_cast<unsigned*>(lds.lohi + kRB);
+  lds.bm = bm0 + g * (kRB * 2);
+  lds.skip = reinterpret_cast<int*>(bm0 + 2 * kRB * 2);
   lds.tI = lds.skip + kRB;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
-  const int li = lane & 31, lh = lane >> 5;
-  const int srow = t >> 2, qt = t & 3;
+  lds.tP = lds.tI + kRB;
   const int k = d >> 1;
+#ifdef GE_RANK_STAMPS
+  long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = 0;
+#endif
 
-  // this workgroup's share of the (row block, candidate tile) list, row-block major
-  int64_t idx = n_tiles * blockIdx.x / gridDim.x;
-  const int64_t idx_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+  // This workgroup's share of the (row block, 128-candidate tile) list, row-block major -- walked so that every
+  // workgroup of the chip starts at candidate tile 0 and sweeps upwards at the same pace: the share's FIRST row block
+  // (entered at some tile ct_a > 0) is taken last.  The CUs of an XCD then read the same tiles of `planes` within a
+  // few tiles of each other and the XCD's 4 MiB L2 serves all but the first of them; walked in list order the 32 CUs
+  // sat at 32 different places of the candidate ring, the planes (13 MB) streamed through every L2 and 80 % of the
+  // reads missed it (TCC_HIT / TCC_MISS, profiles/r03_rank_profile.txt): 3.7 TB/s of Infinity-Cache reads with 32 KB
+  // in flight per CU was what bounded the sweep.
+  const int64_t share0 = n_tiles * blockIdx.x / gridDim.x, share1 = n_tiles * (blockIdx.x + 1) / gridDim.x;
+  const int64_t first_end = min(share1, (share0 / n_ct + 1) * n_ct);
+  for (int pass = 0; pass < 2; ++pass) {
+  int64_t idx = pass ? share0 : first_end;
+  const int64_t idx_end = pass ? first_end : share1;
   while (idx < idx_end) {
     const int rb = (int)(idx / n_ct);
     const int ct0 = (int)(idx - (int64_t)rb * n_ct);
@@ -277,7 +273,8 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     // ---- Q = fixed o relation for the block's 128 rows (four threads a row), scaled by the rows' clip scales and
     // 2^8, split into two fp16 planes
     {
-      const int64_t r = m0 + srow;
+      const int qrow = t >> 2;
+      const int64_t r = m0 + qrow;
       int32_t fid = -1, rid = -1;
       if (r < B) { fid = hr[2 * r]; rid = hr[2 * r + 1]; }
       const bool bad = fid < 0 || fid >= N || rid < 0 || rid >= N;
@@ -302,8 +299,8 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       // product d max_norm^2: the 1/d of the correlation theorem is folded in BEFORE the split (|q sa / d| <= max_norm^2),
       // which keeps every plane entry below 2^8 * 64 for max_norm <= 8 whatever the table holds.
       const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d * kQScale;
-      _Float16* ah = lds.Ah + srow * kSA;
-      _Float16* am = lds.Am + srow * kSA;
+      _Float16* ah = lds.Ah + qrow * kSA;
+      _Float16* am = lds.Am + qrow * kSA;
       for (int j = qt; j < (k >> 2); j += 4) {                   // pass 2: q * sa * 2^8 -> high halves and remainders
         const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
         const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
@@ -339,16 +336,18 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       }
       if (qt == 0) {
         for (int c = d; c < 16 * KKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }       // k padding
-        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
-        lds.skip[srow] = 0;
-        lds.tI[srow] = (MODE != 2 && r < B) ? true_id[r] : -1;
+        lds.sA[qrow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
+        lds.skip[qrow] = 0;
+        const int32_t tid = (MODE != 2 && r < B) ? true_id[r] : -1;
+        lds.tI[qrow] = tid;
+        lds.tP[qrow] = (tid >= 0 && tid < N) ? pos_of[tid] : -1;
       }
     }
     __syncthreads();
 
-    auto cand_of = [&](int ct) -> int32_t {
-      const int64_t c = (int64_t)ct * kRB + srow;
-      return (ct < ct1 && c < K) ? cand[c] : -1;
+    // this group's tiles: the 64-candidate halves u = 2 ct + g of the share's 128-candidate tiles
+    auto tile_src = [&](int u) -> const _Float16* {               // this thread's 16 bytes of tile u's chunk 0 (clamped)
+      return planes + (int64_t)min(u, n_t64 - 1) * kTileHalves + tg * 8;
     };
     auto known_of = [&](int ct, int32_t& k0, int32_t& k1) {
       k0 = k1 = 0;
@@ -357,30 +356,27 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         k0 = known_off[tile]; k1 = known_off[tile + 1];
       }
     };
-    auto row_of = [&](int32_t id) -> const float* {               // (bad ids read row 0; their clip scale is NaN)
-      return table + (int64_t)((id < 0 || id >= N) ? 0 : id) * d;
-    };
-    auto fetch_row = [&](const float* row, HRow<KKB>& R) {
-#pragma unroll
-      for (int c = 0; c < kChunks; ++c) h_fetch_slot<KKB>(row, d, qt, c, R.r[c]);
-      R.x_dc = row[0];
-      R.x_ny = row[d >> 1];
-    };
     f32x16 acc[2];
-    HRow<KKB> R;
-    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = 0;
-    (void)st_; (void)tp_;
-    // ---- the true candidates: a tile whose candidate rows are this block's 128 true entities
+    HL L[2];
+    const int u0 = 2 * ct0 + g;
+    // ---- the true candidates: for each group a tile whose candidate rows are 64 of the block's true entities (both
+    // groups run it in the same phase)
     if constexpr (MODE != 2) {
-      const int32_t tid = lds.tI[srow];
-      fetch_row(row_of(tid), R);
-      h_tile<KKB>(row_of(cand_of(ct0)), d, tid < 0 || tid >= N, max_norm, spec, lds, R, acc, st_, tp_);   // leaves the first tile's row in R
+      const int pos = lds.tP[g * kCT + srow];
+      const int pc = pos < 0 ? 0 : pos;
+      const _Float16* dsrc = planes + (int64_t)(pc >> 6) * kTileHalves + (pc & 63) * 32 + qt * 8;
+      h_load(L[0], dsrc, 0);
+      h_load(L[1], dsrc, 1);
+      h_write(lds, L[0], srow, qt, 0);
+      h_refill<KKB, -1>(L, dsrc, tile_src(u0));
+      __syncthreads();
+      h_mfma_loop<KKB>(lds, dsrc, tile_src(u0), L, acc, srow, qt, wm, wn, li, lh);   // leaves the first tile's chunks 0 / 1 in L
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-          if (rl == wn * 32 + li) lds.eT[rl] = acc[tm][q];        // raw score, row scale still to come
+          if (rl == g * kCT + wn * 32 + li) lds.eT[rl] = acc[tm][q];   // raw score, row scale still to come
         }
       __syncthreads();
       if (t < kRB) {
@@ -390,8 +386,9 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         // differs by >= 0.9e-6, three times what the roundings of x * sA and of the 4-instruction sigmoid
         // (< 1.5e-7 each side) can move: outside the bracket the order of the losses is the order of the raw scores.
         // Near saturation (g < 1e-5, |score| > 11.5) no finite bracket gives that margin: it is infinite there and
-        // every candidate of the row takes the exact comparison.
-        const float xp = lds.eT[t], sa = lds.sA[t];
+        // every candidate of the row takes the exact comparison.  A true entity that is not among the candidates has
+        // no rank: NaN bracket, NaN loss, no bit is ever set.
+        const float xp = lds.tP[t] < 0 ? __builtin_nanf("") : lds.eT[t], sa = lds.sA[t];
         const float xs = xp * sa, e = rank_sigmoid(xs), gs = e * (1.0f - e);
         const float wx = gs < 1e-5f ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
         const float wq = wx / sa;
@@ -399,117 +396,223 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         lds.eT[t] = e;
         if (true_loss && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
       }
-      __syncthreads();
+      // (the barrier that opens the sweep, below, publishes the brackets)
+    } else {
+      h_load(L[0], tile_src(u0), 0);
+      h_load(L[1], tile_src(u0), 1);
     }
     int raw_reg = 0;
 
-    // ---- the sweep over this share's candidate tiles of the row block
-    // candidate ids and known-cell ranges are requested one tile ahead of their use: nothing ever waits on them
-    int32_t cid = cand_of(ct0), cid_next = cand_of(ct0 + 1), kn0, kn1, kn0_next, kn1_next;
+    // ---- the sweep: this group's ct1 - ct0 tiles, one cycle of kCycle barriers each, group 1 half a cycle behind
+    int32_t kn0, kn1, kn0_next, kn1_next;
     known_of(ct0, kn0_next, kn1_next);
-    if constexpr (MODE == 2) fetch_row(row_of(cid), R);          // no diagonal tile ran: the first row is not in R yet
+    h_write(lds, L[0], srow, qt, 0);
+    h_refill<KKB, -1>(L, tile_src(u0), tile_src(u0 + 2));
+    __syncthreads();
+    if (g == 1) {
+#pragma unroll
+      for (int i = 0; i < kCycle / 2; ++i) __builtin_amdgcn_s_barrier();
+    }
 #ifdef GE_RANK_STAMPS
-    for (int i = 0; i < 8; ++i) st_[i] = 0;
     tp_ = __builtin_readcyclecounter();
 #endif
     for (int ct = ct0; ct < ct1; ++ct) {
-      const int64_t n0 = (int64_t)ct * kRB;
-      h_tile<KKB>(row_of(cid_next), d, cid < 0 || cid >= N, max_norm, spec, lds, R, acc, st_, tp_);
-      cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
-      cid_next = cand_of(ct + 2);
-      known_of(ct + 1, kn0_next, kn1_next);
-      // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-      // A candidate beyond K or with a bad id has a NaN clip scale, a row beyond B a NaN bracket: no bit is set.
-      const int cl = wn * 32 + li;
-      const int64_t col = n0 + cl;
-      if constexpr (MODE == 2) {                                 // scores only: 32 consecutive floats of a row per half-wave
+      const int u = 2 * ct + g;
+      const int64_t col = (int64_t)u * kCT + wn * 32 + li;       // this lane's candidate
+      const _Float16* cur = tile_src(u);
+      const _Float16* nxt = tile_src(u + 2);
+      h_mfma_loop<KKB>(lds, cur, nxt, L, acc, srow, qt, wm, wn, li, lh);
+      // The brackets of this lane's 32 rows, requested together (the operand registers of the MFMA loop are free now):
+      // read score by score -- a wait on the LDS queue, which the other group's operand reads keep busy, in front of
+      // every compare sequence -- the epilogue took 200 cycles per score (measured, tools/probes/rank_phase_probe.py).
+      float2 br[2][16];
+      if constexpr (MODE == 0) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
+          for (int q = 0; q < 16; ++q) br[tm][q] = lds.lohi[wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh];
+      }
+      GE_STAMP(0);
+      kn0 = kn0_next; kn1 = kn1_next;
+      known_of(ct + 1, kn0_next, kn1_next);
+      // epilogue in four pieces (tm, half of the accumulator registers), a barrier behind each: C layout of the
+      // 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  A candidate beyond K or with a bad id
+      // has NaN planes, a row beyond B a NaN bracket: no bit is set.
+      int M = 0;                                                 // lane r: the 32 column bits of row r of the 32 x 32 block
+      unsigned I = 0;                                            // per-lane bitmap of "inside the bracket"
+      int32_t c0 = -1;
+      if constexpr (SCORES) c0 = col < K ? cand[col] : -1;
+      (void)M; (void)I; (void)c0;
+      static_for<0, 4>([&](auto ec) {
+        constexpr int piece = decltype(ec)::value, tm = piece >> 1, q0 = (piece & 1) * 8;
+        unsigned* mrow = lds.bm + (wm * 64 + tm * 32) * 2 + wn;
+        (void)mrow;
+        if constexpr (MODE == 2) {                               // scores only: 32 consecutive floats of a row per half-wave
+#pragma unroll
+          for (int q = q0; q < q0 + 8; ++q) {
             const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
             const int64_t row = m0 + rl;
             float v = acc[tm][q] * lds.sA[rl];
             if (sweep_flags & 1) v = rank_sigmoid(v);            // 4 VALU, within 3e-7 of expf's
             if (row < B && col < K) scores_out[row * K + col] = v;
           }
-        continue;
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        int M = 0;                                               // lane r: the 32 column bits of row r of the 32 x 32 block
-        unsigned* mrow = lds.bm + (wm * 64 + tm * 32) * 4 + wn;
-        if constexpr (SCORES) {                                  // tests: every loss exactly, and stored
-          const int32_t c0 = col < K ? cand[col] : -1;
-          static_for<0, 16>([&](auto qc) {
+        } else if constexpr (SCORES) {                           // tests: every loss exactly, and stored
+          static_for<q0, q0 + 8>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
             const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
             const float et = lds.eT[rl];
             const float e0 = rank_sigmoid(acc[tm][q] * lds.sA[rl]);
             const unsigned long long mk = __ballot(e0 < et) | __ballot(e0 == et && c0 < lds.tI[rl]);
             if (m0 + rl < B && col < K) scores_out[(m0 + rl) * K + col] = e0;
-            set_lane<R32>(M, (unsigned)mk);
+            set_lane<R32>(M, (unsigned)mk);                      // (mk comes out of a scalar OR: no VALU -> VALU SGPR hazard)
             set_lane<R32 + 4>(M, (unsigned)(mk >> 32));
           });
-          if (lane < 32) mrow[lane * 4] = (unsigned)M;
+          if constexpr (piece & 1) {
+            if (lane < 32) mrow[lane * 2] = (unsigned)M;
+            M = 0;
+          }
         } else {
           // Per score: "x < lo" (the bit, as a wave mask -> two v_writelane) and "x <= hi"; the scores inside the bracket
           // (le and not lt: one scalar and-not) are shifted into a per-lane bitmap (one v_addc): bracket_item.  Longer
           // scalar chains on compare results (compare / select / or per score) stall the wave: measured.
-          unsigned I = 0;                                        // per-lane bitmap of "inside the bracket"
-          static_for<0, 16>([&](auto qc) {
+          static_for<q0, q0 + 8>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
-            bracket_item<R32>(acc[tm][q], lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh], M, I);   // (the planes carry the clip scale)
+            if constexpr ((GE_RANK_X & 32) && (q & 7)) return;   // diagnostic: one score in eight
+            if constexpr (!(GE_RANK_X & 1)) bracket_item<R32>(acc[tm][q], br[tm][q], M, I);   // (the planes carry the clip scale)
+            else { I += acc[tm][q] < br[tm][q].x ? 1u : 0u; M += acc[tm][q] <= br[tm][q].y ? 1 : 0; }
           });
-          if (lane < 32) mrow[lane * 4] = (unsigned)M;
-          if (I) {                                               // lanes owning a score inside a bracket: the exact
-            static_for<0, 4>([&](auto gc) {                      // comparison, bit set in LDS; 4 scores per outer test
-              constexpr int g4 = decltype(gc)::value;
-              if (I & (0xf000u >> (4 * g4))) {
-                static_for<0, 4>([&](auto kc) {
-                  constexpr int q = 4 * g4 + decltype(kc)::value, R32 = (q & 3) + 8 * (q >> 2);
-                  if (I & (0x8000u >> q)) {
-                    const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
-                    const float e = rank_sigmoid(acc[tm][q] * lds.sA[rl]), et = lds.eT[rl];
-                    bool before = e < et;
-                    if (e == et) before = (col < K ? cand[col] : -1) < lds.tI[rl];   // equal losses pop in id order
-                    if (before) atomicOr(mrow + (R32 + 4 * lh) * 4, 1u << li);
-                  }
-                });
-              }
-            });
+          if constexpr (piece & 1) {
+            if (lane < 32) mrow[lane * 2] = (unsigned)M;
+            if (I) {                                             // lanes owning a score inside a bracket: the exact
+              static_for<0, 4>([&](auto gc) {                    // comparison, bit set in LDS; 4 scores per outer test
+                constexpr int g4 = decltype(gc)::value;
+                if (I & (0xf000u >> (4 * g4))) {
+                  static_for<0, 4>([&](auto kc) {
+                    constexpr int q = 4 * g4 + decltype(kc)::value, R32 = (q & 3) + 8 * (q >> 2);
+                    if (I & (0x8000u >> q)) {
+                      const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
+                      const float e = rank_sigmoid(acc[tm][q] * lds.sA[rl]), et = lds.eT[rl];
+                      bool before = e < et;
+                      if (e == et) before = (col < K ? cand[col] : -1) < lds.tI[rl];   // equal losses pop in id order
+                      if (before) atomicOr(mrow + (R32 + 4 * lh) * 2, 1u << li);
+                    }
+                  });
+                }
+              });
+            }
+            M = 0; I = 0;
+          }
+        }
+        __syncthreads();
+      });
+      GE_STAMP(1);
+      // the tile's bitmap is complete in LDS: rows count their bits, known cells that rank before the target are tallied
+      if constexpr (MODE != 2) {
+        if (tg < kRB) {
+          const unsigned* m = lds.bm + tg * 2;
+          raw_reg += __popc(m[0]) + __popc(m[1]);
+        }
+        if (known_off) {
+          for (int32_t e = kn0 + tg; e < kn1; e += kGrp) {
+            const unsigned rc = known_rc[e];
+            const int rl = rc >> 7, cl = rc & 127;
+            if ((cl >> 6) == g && ((lds.bm[rl * 2 + ((cl >> 5) & 1)] >> (cl & 31)) & 1u)) atomicAdd(&lds.skip[rl], 1);
           }
         }
       }
-      GE_STAMP(4, tp_);
+      // the next tile's chunk 0 (every wave of the group has left this tile's MFMA loop: four barriers ago)
+      h_write(lds, L[0], srow, qt, 0);
+      h_refill<KKB, -1>(L, nxt, tile_src(u + 4));
       __syncthreads();
-      GE_STAMP(5, tp_);
-      // the tile's bitmap is complete in LDS: rows count their bits, known cells that rank before the target are tallied
-      if (t < kRB) {
-        const unsigned* m = lds.bm + t * 4;
-        raw_reg += __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
-      }
-      if (known_off) {
-        for (int32_t e = kn0 + t; e < kn1; e += kBlk) {
-          const unsigned rc = known_rc[e];
-          const int rl = rc >> 7, cl2 = rc & 127;
-          if ((lds.bm[rl * 4 + (cl2 >> 5)] >> (cl2 & 31)) & 1u) atomicAdd(&lds.skip[rl], 1);
-        }
-      }
-      GE_STAMP(6, tp_);
-      // no barrier: the next tile's first write to bm comes after its own barriers
+#pragma unroll
+      for (int i = 0; i < HCfg<KKB>::kPad; ++i) __builtin_amdgcn_s_barrier();
+      GE_STAMP(2);
     }
-#ifdef GE_RANK_STAMPS
-    if (lane == 0) {
-      for (int i = 0; i < 7; ++i) atomicAdd(&g_rank_stamps[i], (unsigned long long)st_[i]);
-      atomicAdd(&g_rank_stamps[7], (unsigned long long)(ct1 - ct0));
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < kCycle / 2; ++i) __builtin_amdgcn_s_barrier();
     }
-#endif
     __syncthreads();
-    if (MODE != 2 && t < kRB && m0 + t < B) {
-      if (raw_reg) atomicAdd(&raw_cnt[m0 + t], raw_reg);
-      if (lds.skip[t]) atomicAdd(&skip_cnt[m0 + t], lds.skip[t]);
+    if (MODE != 2 && tg < kRB && m0 + tg < B) {
+      if (raw_reg) atomicAdd(&raw_cnt[m0 + tg], raw_reg);
+      if (g == 0 && lds.skip[tg]) atomicAdd(&skip_cnt[m0 + tg], lds.skip[tg]);
     }
+  }
+  }
+#ifdef GE_RANK_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < 3; ++i) atomicAdd(&g_rank_stamps[i + 4 * g], (unsigned long long)st_[i]);
+    atomicAdd(&g_rank_stamps[3 + 4 * g], 1ull);
+  }
+#endif
+}
+
+// ---- the pre-pass: candidate planes.  Tile T = 64 candidates, chunk c = 32 columns:
+//   planes[((T * kChunks + c) * 2 + plane) * 64 * 32 + row * 32 + column]   fp16
+// = high halves / remainders of cand row * clip scale * 2^8 (0 behind embedding_dim; NaN for a bad id or a row behind K).
+template <int KKB>
+__global__ __launch_bounds__(kGrp) void rank_planes_kernel(const float* __restrict__ table, int64_t N, int d,
+                                                           const int32_t* __restrict__ cand, int64_t K, float max_norm,
+                                                           int spec, _Float16* __restrict__ planes) {
+  constexpr int kChunks = HCfg<KKB>::kChunks;
+  const int srow = threadIdx.x >> 2, qt = threadIdx.x & 3;
+  const int64_t T = blockIdx.x, pos = T * kCT + srow;
+  const int32_t id = pos < K ? cand[pos] : -1;
+  const bool bad = id < 0 || id >= N;
+  const float* row = table + (int64_t)(bad ? 0 : id) * d;
+  float4 r[kChunks][2];
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    const int col = min(c * 32 + qt * 8, d - 8);                 // clamped into the row, zeroed below
+    r[c][0] = *reinterpret_cast<const float4*>(row + col);
+    r[c][1] = *reinterpret_cast<const float4*>(row + col + 4);
+  }
+  f2 ss2 = {0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    const bool in = c * 32 + qt * 8 < d;                         // (embedding_dim % 8 == 0: all eight or none)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const f2 xy = in ? f2{r[c][v].x, r[c][v].y} : f2{0.f, 0.f}, zw = in ? f2{r[c][v].z, r[c][v].w} : f2{0.f, 0.f};
+      ss2 = __builtin_elementwise_fma(xy, xy, ss2);
+      ss2 = __builtin_elementwise_fma(zw, zw, ss2);
+    }
+  }
+  float ss = ss2.x + ss2.y;
+  ss += __shfl_xor(ss, 1, kWave);
+  ss += __shfl_xor(ss, 2, kWave);
+  // spectral HolE rows: |x|^2 = (2 sum - X_0^2 - X_k^2) / d; the two real bins sit at columns 0 and d/2
+  if (spec) {
+    const float x_dc = row[0], x_ny = row[d >> 1];
+    ss = (2.f * ss - x_dc * x_dc - x_ny * x_ny) / (float)d;
+  }
+  float inv;
+  // t * clip(t) * 2^8: |t clip| <= max_norm, or max_norm sqrt(d/2) for one bin of a spectral row -- no fp16 overflow
+  // for max_norm <= 8 whatever the table holds
+  const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
+  _Float16* dst = planes + T * (int64_t)kChunks * kChunkHalves + srow * 32 + qt * 8;
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    const bool in = bad || c * 32 + qt * 8 < d;                  // (a bad row is NaN everywhere)
+    const float x[8] = {r[c][0].x, r[c][0].y, r[c][0].z, r[c][0].w, r[c][1].x, r[c][1].y, r[c][1].z, r[c][1].w};
+    h8 hi, mid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h2 a, b;
+      h_split(in ? x[2 * i] * scale : 0.f, in ? x[2 * i + 1] * scale : 0.f, a, b);
+      hi[2 * i] = a.x; hi[2 * i + 1] = a.y; mid[2 * i] = b.x; mid[2 * i + 1] = b.y;
+    }
+    *reinterpret_cast<h8*>(dst + c * kChunkHalves) = hi;
+    *reinterpret_cast<h8*>(dst + c * kChunkHalves + kCT * 32) = mid;
+  }
+}
+
+// pos_of[entity] = its position in `cand` (-1, from the memset before: none)
+__global__ void rank_pos_kernel(const int32_t* __restrict__ cand, int64_t K, int64_t N, int32_t* __restrict__ pos_of) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K) {
+    const int32_t id = cand[i];
+    if (id >= 0 && id < N) pos_of[id] = (int32_t)i;
   }
 }
 
@@ -520,22 +623,28 @@ int f16_cu_count() {
   return cus;
 }
 
+inline bool f16_dim_ok(int32_t d, float max_norm) { return d % 8 == 0 && d >= 56 && d <= 208 && max_norm <= 8.f; }
+inline int64_t pos_bytes(int64_t N) { return (N * (int64_t)sizeof(int32_t) + 255) / 256 * 256; }
+inline int64_t planes_tiles(int64_t K) { return 2 * ((K + kRB - 1) / kRB); }   // 64-candidate tiles, an even number
+
 template <int KKB>
 int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                    const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                    const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss, float* scores_out,
-                   int spec, int scores_only, int sweep_flags, hipStream_t st) {
+                   int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
-  if (n_ct > INT32_MAX / 2 || n_rb > INT32_MAX / 2) return GE_ENOTSUP;
+  if (n_ct > INT32_MAX / 4 || n_rb > INT32_MAX / 4) return GE_ENOTSUP;
   const int64_t n_tiles = n_rb * n_ct;
   const int64_t grid = std::min<int64_t>(n_tiles, GE_PIPE_GRID_M * (int64_t)f16_cu_count());
+  const int32_t* pos_of = reinterpret_cast<const int32_t*>(planes_ws);
+  const _Float16* planes = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(planes_ws) + pos_bytes(N));
   auto go = [&](auto kern) -> int {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlk), h_lds_bytes<KKB>(), st, table, N, d, hr, B, true_id, cand, K,
                        max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct,
-                       n_tiles, spec, sweep_flags);
+                       n_tiles, spec, sweep_flags, pos_of, planes);
     return launch_status();
   };
   if (scores_only) return go(rank_f16_kernel<KKB, 2>);
@@ -556,23 +665,72 @@ extern "C" int ge_debug_rank_stamps(unsigned long long* out, int reset) {
 }
 #endif
 
+#define GE_KKB_SWITCH(d, CALL)                                                                        \
+  switch (((d) + 15) / 16) {                                                                          \
+    case 4: CALL(4); case 5: CALL(5); case 6: CALL(6); case 7: CALL(7); case 8: CALL(8);              \
+    case 9: CALL(9); case 10: CALL(10); case 11: CALL(11); case 12: CALL(12); case 13: CALL(13);      \
+    default: return GE_ENOTSUP;                                                                       \
+  }
+
+// bytes of the candidate planes of a K-candidate sweep over an N-row table (0: embedding_dim has no split-precision sweep)
+int64_t rank_planes_bytes(int64_t N, int32_t d, int64_t K) {
+  if (d % 8 != 0 || d < 56 || d > 208 || N <= 0 || K <= 0) return 0;
+  const int64_t kchunks = ((d + 15) / 16 + 1) / 2;
+  return pos_bytes(N) + planes_tiles(K) * kchunks * kChunkHalves * (int64_t)sizeof(_Float16);
+}
+
+// planes_ws (rank_planes_bytes, 256-byte aligned) <- the entity -> position map, then the candidates' fp16 planes
+int rank_planes_launch(const float* table, int64_t N, int32_t d, const int32_t* cand, int64_t K, float max_norm, int spec,
+                       void* planes_ws, hipStream_t st) {
+  if (!f16_dim_ok(d, max_norm)) return GE_ENOTSUP;
+  if (reinterpret_cast<uintptr_t>(planes_ws) % 256 != 0 || reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
+  if (K <= 0 || N <= 0) return 0;
+  int32_t* pos_of = reinterpret_cast<int32_t*>(planes_ws);
+  _Float16* planes = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(planes_ws) + pos_bytes(N));
+  hipError_t e = hipMemsetAsync(pos_of, 0xff, (size_t)N * sizeof(int32_t), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(rank_pos_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, cand, K, N, pos_of);
+  const int64_t n_t64 = planes_tiles(K);
+  if (n_t64 > INT32_MAX) return GE_ENOTSUP;
+#define GE_CALL(KKB)                                                                                                   \
+  hipLaunchKernelGGL(rank_planes_kernel<KKB>, dim3((unsigned)n_t64), dim3(kGrp), 0, st, table, N, d, cand, K, max_norm, \
+                     spec, planes);                                                                                    \
+  return launch_status()
+  GE_KKB_SWITCH(d, GE_CALL)
+#undef GE_CALL
+}
+
 // The split-precision sweep: embedding_dim % 8 == 0 in 56 ... 208 (k blocks 4 ... 13), max_norm <= 8
 // (|q sa (1/d)| <= 2 max_norm^2, |t clip| <= max_norm sqrt(d/2): x 2^8 inside fp16).  GE_ENOTSUP otherwise.
+// planes_ws: the candidates' planes from rank_planes_launch for the same (table, cand, max_norm, spec), or NULL -- then
+// they are built here in a stream-ordered allocation (one more pass over the K candidate rows).
 int sweep_f16_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                     float* scores_out, int spec, int scores_only, int sweep_flags, hipStream_t st) {
-  if (d % 8 != 0 || d < 56 || d > 208 || !(max_norm <= 8.f)) return GE_ENOTSUP;
+                     float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
+  if (!f16_dim_ok(d, max_norm)) return GE_ENOTSUP;
   static_assert(h_lds_bytes<13>() <= 160 * 1024, "LDS of the largest instantiation");
-#define GE_KKB(KKB)                                                                                                  \
-  case KKB:                                                                                                          \
-    return f16_launch_kkb<KKB>(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,   \
-                               raw_cnt, skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, st)
-  switch ((d + 15) / 16) {
-    GE_KKB(4); GE_KKB(5); GE_KKB(6); GE_KKB(7); GE_KKB(8); GE_KKB(9); GE_KKB(10); GE_KKB(11); GE_KKB(12); GE_KKB(13);
-    default: return GE_ENOTSUP;
+  void* own = nullptr;
+  if (!planes_ws) {
+    hipError_t e = hipMallocAsync(&own, (size_t)rank_planes_bytes(N, d, K), st);
+    if (e != hipSuccess) return (int)e;
+    const int rc = rank_planes_launch(table, N, d, cand, K, max_norm, spec, own, st);
+    if (rc != 0) { (void)hipFreeAsync(own, st); return rc; }
+    planes_ws = own;
   }
-#undef GE_KKB
+  auto run = [&]() -> int {
+#define GE_CALL(KKB)                                                                                                 \
+  return f16_launch_kkb<KKB>(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,       \
+                             raw_cnt, skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, planes_ws, st)
+    GE_KKB_SWITCH(d, GE_CALL)
+#undef GE_CALL
+  };
+  int rc = run();
+  if (own) {
+    const hipError_t e = hipFreeAsync(own, st);
+    if (rc == 0 && e != hipSuccess) rc = (int)e;
+  }
+  return rc;
 }
 
 }  // namespace ge

@@ -819,30 +819,30 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
 }  // namespace
 
 int sweep_pipe_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float,
-                      int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, int, int, hipStream_t);
+                      int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, int, int, const void*, hipStream_t);
 
 int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                     float* scores_out, int spec, hipStream_t st) {
+                     float* scores_out, int spec, const void* planes_ws, hipStream_t st) {
   return sweep_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
-                           skip_cnt, true_loss, scores_out, spec, 0, 0, st);
+                           skip_cnt, true_loss, scores_out, spec, 0, 0, planes_ws, st);
 }
 
 // ge_complex_score_1vK on the same pipeline: out [B,K] = score (sigmoid when apply_sigmoid)
 int score_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* cand,
                       int64_t K, float max_norm, int apply_sigmoid, int cand_is_head, float* out, hipStream_t st) {
   return sweep_pipe_launch(table, N, d, hr, B, nullptr, cand, K, max_norm, cand_is_head, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, out, 0, 1, apply_sigmoid ? 1 : 0, st);
+                           nullptr, out, 0, 1, apply_sigmoid ? 1 : 0, nullptr, st);
 }
 
 int sweep_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                       const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                       const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                      float* scores_out, int spec, int scores_only, int sweep_flags, hipStream_t st) {
+                      float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
   if (!getenv("GE_RANK_F16_OLD")) {
     const int rc = sweep_f16_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
-                                    skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, st);
+                                    skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, planes_ws, st);
     if (rc != GE_ENOTSUP) return rc;
   }
 #define GE_PIPE(CW)                                                                                                  \

@@ -75,7 +75,7 @@ class KnownIndex:
 @torch.no_grad()
 def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, candidates: np.ndarray,
                           known_triples: np.ndarray = None, side: str = "tail", batch: int = None,
-                          max_norm: float = 1.0, fused: bool = None, model: str = "complex"):
+                          max_norm: float = 1.0, fused: bool = None, model: str = "complex", planes=None):
     """Raw and filtered rank of every test triple's true entity among `candidates`, with the
     semantics of holE.py:446-469.  side="tail": candidates replace the tail; "head": the head.
     Returns (raw_ranks, filtered_ranks) int64 arrays.  The true entity must be a candidate.
@@ -84,7 +84,9 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
     of ge_complex_score_1vK are ranked with tensor ops.
     model: "complex"; "hole" (README.md:42 on a real-valued table: a copy is taken to the frequency domain once,
     where HolE is the ComplEx-shaped form the sweep computes) or "hole_spectral" (table already there).  HolE
-    needs the fused sweep."""
+    needs the fused sweep.
+    planes: H.RankPlanes of (embeddings, candidates) shared between calls (tails then heads: evaluate_fb15k_style); built
+    here otherwise -- once for all the batches of the call."""
     assert side in ("tail", "head")
     if model not in ("complex", "hole", "hole_spectral"):
         raise ValueError(f"unknown model {model!r}")
@@ -112,6 +114,12 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
         batch = 1 << 17 if fused else 16384
     raw_all, fil_all = [], []
     fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
+    if fused and planes is None:
+        planes = H.RankPlanes(embeddings, cand, max_norm=max_norm, model=model)
+    if planes is not None:
+        if planes.cand.numel() != cand.numel():
+            raise ValueError("`planes` were built for another candidate list")
+        cand = planes.cand
     for s in range(0, len(test), batch):
         chunk = torch.as_tensor(test[s:s + batch]).to(dev)
         fixed, rel, true_id = chunk[:, fixed_col], chunk[:, 2], chunk[:, true_col]
@@ -122,7 +130,7 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
         off, rc = index.cells(fixed, rel, pos_of, cand.numel())
         if fused:
             n_before, n_known = H.rank_candidates(embeddings, hr, true_id, cand, known_off=off, known_rc=rc,
-                                                  cand_is_head=(side == "head"), max_norm=max_norm, model=model)
+                                                  cand_is_head=(side == "head"), max_norm=max_norm, model=model, planes=planes)
             raw = n_before.to(torch.int64) + 1
             fil = raw - n_known.to(torch.int64)
         else:
@@ -156,10 +164,14 @@ def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True
     known = np.concatenate(parts, 0) if parts else None
     if model == "hole":                      # one transform for both sides
         embeddings, model = H.hole_to_spectral(embeddings.detach().clone()), "hole_spectral"
-    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known, "tail", batch, model=model)
+    d = embeddings.shape[1]
+    planes = None                            # the candidates' fp16 planes: one build for tails and heads
+    if d % 8 == 0 and d <= H.rank_max_dim():
+        planes = H.RankPlanes(embeddings, torch.as_tensor(cand).to(embeddings.device), model=model)
+    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known, "tail", batch, model=model, planes=planes)
     raw, fil = [raw_t], [fil_t]
     if both_sides:
-        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known, "head", batch, model=model)
+        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known, "head", batch, model=model, planes=planes)
         raw.append(raw_h); fil.append(fil_h)
     out = mrr_and_hits(np.concatenate(raw), np.concatenate(fil))
     if verbose:

@@ -323,16 +323,39 @@ def rank_max_dim() -> int:
     return int(_lib.load().ge_rank_max_dim())
 
 
+class RankPlanes:
+    """The candidates of a ranking sweep as the split-precision kernel reads them (ge_rank_planes: fp16 high halves and
+    remainders of row * clip scale * 2^8 per 64-candidate tile, plus the entity -> position map), built ONCE for all the
+    batches -- tails and heads -- ranked against the same (table, candidates, max_norm, model).  `buffer` is None when
+    embedding_dim has no split-precision sweep (rank_candidates then ignores it).  Rebuild after the table changes."""
+
+    def __init__(self, embeddings: torch.Tensor, candidates: torch.Tensor, *, max_norm: float = 1.0, model: str = "complex"):
+        if model not in ("complex", "hole_spectral"):
+            raise ValueError("RankPlanes: model must be 'complex' or 'hole_spectral'")
+        emb = _table(embeddings)
+        _need_cuda(candidates, "candidates")
+        self.cand = candidates.to(torch.int32).contiguous().view(-1)
+        self.key = (emb.data_ptr(), emb.shape[0], emb.shape[1], self.cand.data_ptr(), self.cand.numel(), float(max_norm), model)
+        nbytes = int(_lib.load().ge_rank_planes_bytes(emb.shape[0], emb.shape[1], self.cand.numel())) if max_norm <= 8.0 else 0
+        self.buffer = None
+        if nbytes > 0:
+            self.buffer = torch.empty(nbytes, dtype=torch.uint8, device=emb.device)     # (the allocator aligns to 256 bytes and more)
+            _lib.call("ge_rank_planes", emb.data_ptr(), emb.shape[0], emb.shape[1], self.cand.data_ptr(), self.cand.numel(),
+                      max_norm, _MODELS[model], self.buffer.data_ptr(), _stream())
+
+
 def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, true_ids: torch.Tensor,
                     candidates: torch.Tensor, *, known_off: Optional[torch.Tensor] = None,
                     known_rc: Optional[torch.Tensor] = None, cand_is_head: bool = False, max_norm: float = 1.0,
-                    return_true_loss: bool = False, return_scores: bool = False, model: str = "complex"):
+                    return_true_loss: bool = False, return_scores: bool = False, model: str = "complex",
+                    planes: Optional[RankPlanes] = None):
     """The candidate sweep of holE.py:564-569 with the ranking of holE.py:427-472 as its epilogue
     (ge_complex_rank_1vK): per test row the number of candidates that pop from the reference's heap before the
     true one (n_before; raw rank = 1 + n_before) and how many of those are known-true (n_known_before; filtered
     rank = raw - n_known_before).  No [B,K] score matrix exists unless return_scores asks for it (tests).
     known_off / known_rc: the per-(128 rows x 128 candidates)-tile lists of known-true cells (evaluate.py).
-    model: "complex", or "hole_spectral" for a table held in the frequency domain (hole_to_spectral)."""
+    model: "complex", or "hole_spectral" for a table held in the frequency domain (hole_to_spectral).
+    planes: RankPlanes(embeddings, candidates, ...) built once for many calls (otherwise the kernel rebuilds them)."""
     if model not in ("complex", "hole_spectral"):
         raise ValueError("rank_candidates: model must be 'complex' or 'hole_spectral' (transform a real HolE table first)")
     emb = _table(embeddings)
@@ -354,11 +377,19 @@ def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, 
         n_tiles = ((B + 127) // 128) * ((K + 127) // 128)
         if known_off.dtype != torch.int32 or known_off.numel() != n_tiles + 1 or known_rc.dtype != torch.int16:
             raise ValueError("known_off must be int32 [tiles+1], known_rc int16 (row%128 << 7 | col%128)")
-    _lib.call("ge_rank_1vK", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), B, tid.data_ptr(),
+    pl = None
+    if planes is not None and planes.buffer is not None:
+        same = planes.key == (emb.data_ptr(), emb.shape[0], emb.shape[1], planes.cand.data_ptr(), K, float(max_norm), model)
+        if same and cand.data_ptr() != planes.cand.data_ptr():      # another tensor: compare the ids (one synchronisation)
+            same = bool(torch.equal(planes.cand, cand))
+        if not same:
+            raise ValueError("rank_candidates: `planes` were built for another table / candidate list / max_norm / model")
+        cand, pl = planes.cand, planes.buffer.data_ptr()
+    _lib.call("ge_rank_1vK_planes", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), B, tid.data_ptr(),
               cand.data_ptr(), K, max_norm, _MODELS[model], int(cand_is_head),
               known_off.data_ptr() if known_off is not None else None,
               known_rc.data_ptr() if known_rc is not None else None, n_before.data_ptr(), n_known.data_ptr(),
-              tl.data_ptr() if tl is not None else None, sc.data_ptr() if sc is not None else None, _stream())
+              tl.data_ptr() if tl is not None else None, sc.data_ptr() if sc is not None else None, pl, _stream())
     out = (n_before, n_known)
     if return_true_loss:
         out += (tl,)

@@ -225,6 +225,23 @@ int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int
                 const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                 float* scores_out, void* stream);
 
+/* The split-precision sweep (embedding_dim % 8 == 0 in 56 ... 208, max_norm <= 8) reads the candidates as pre-split fp16
+ * planes (high halves and remainders of row * clip scale * 2^8, laid out per 64-candidate tile) plus an entity ->
+ * candidate-position map.  ge_rank_1vK builds them on every call (one pass over the K candidate rows, in a
+ * stream-ordered allocation); a caller that ranks many batches against the same (table, cand, max_norm, model) --
+ * holE.py:564-575 sweeps all entities for every test triple, tails and heads -- builds them once:
+ *   ge_rank_planes_bytes   bytes of the buffer (0: this embedding_dim has no such sweep -- pass planes = NULL)
+ *   ge_rank_planes         fills it (256-byte aligned); valid until the table, cand or max_norm change
+ *   ge_rank_1vK_planes     ge_rank_1vK with the buffer (NULL: as ge_rank_1vK).  cand_is_head does not enter the planes.
+ * A true_id that is not in `cand` has no rank: n_before = n_known_before = 0, true_loss NaN (all kernels). */
+int64_t ge_rank_planes_bytes(int64_t N, int32_t d, int64_t K);
+int ge_rank_planes(const float* table, int64_t N, int32_t d, const int32_t* cand, int64_t K, float max_norm, int model,
+                   void* planes, void* stream);
+int ge_rank_1vK_planes(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
+                       const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head, const int32_t* known_off,
+                       const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
+                       float* scores_out, const void* planes, void* stream);
+
 /* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
  * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already
  * shuffled [T,3] int32 array, wrapping to row 0 when the next batch would run past T -- the

@@ -11,20 +11,20 @@ test = inf.test_array
 cand = torch.arange(inf.relation_count, inf.entity_count, dtype=torch.int32).cuda()
 hr = torch.as_tensor(np.stack([test[:, 0], test[:, 2]], 1).astype(np.int32)).cuda()
 tid = torch.as_tensor(test[:, 1].astype(np.int32)).cuda()
-H.rank_candidates(emb, hr, tid, cand)
+planes = H.RankPlanes(emb, cand)
+H.rank_candidates(emb, hr, tid, cand, planes=planes)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 lib.ge_debug_rank_stamps(buf, 1)
 ev = H.Events(2); ev.record(0)
-H.rank_candidates(emb, hr, tid, cand)
+H.rank_candidates(emb, hr, tid, cand, planes=planes)
 ev.record(1); torch.cuda.synchronize()
 lib.ge_debug_rank_stamps(buf, 0)
 v = list(buf)
-tiles = v[7]            # summed over waves: tiles x 8 waves x (blocks)
-names = ["norm+stash slot 0", "barrier 1", "MFMA loop (incl. its barriers)", "barrier behind the loop", "epilogue", "barrier behind it", "count"]
-print(f"kernel {ev.elapsed_ms(0, 1):.3f} ms; tile-waves {tiles}")
-tot = 0
-for n, c in zip(names, v[:7]):
-    print(f"  {n:34s} {c / tiles:9.0f} cycles per tile per wave")
-    tot += c / tiles
-print(f"  {'sum':34s} {tot:9.0f}")
+print(f"kernel {ev.elapsed_ms(0, 1):.3f} ms")
+names = ["MFMA loop (incl. its barriers)", "epilogue pieces + their barriers", "count, next chunk 0, barrier(s)"]
+for g in (0, 1):
+    waves = v[3 + 4 * g]
+    print(f" group {g}: {waves} waves")
+    for n, c in zip(names, v[4 * g:4 * g + 3]):
+        print(f"  {n:36s} {c / max(waves, 1):12.0f} ticks per wave over the kernel")

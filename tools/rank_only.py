@@ -9,6 +9,7 @@ test = inf.test_array
 hr = torch.as_tensor(np.stack([test[:, 0], test[:, 2]], 1).astype(np.int32)).cuda()
 tid = torch.as_tensor(test[:, 1].astype(np.int32)).cuda()
 c = torch.arange(inf.relation_count, inf.entity_count, dtype=torch.int32, device="cuda")
+planes = H.RankPlanes(emb, c)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    H.rank_candidates(emb, hr, tid, c)
+    H.rank_candidates(emb, hr, tid, c, planes=planes)
 torch.cuda.synchronize()
