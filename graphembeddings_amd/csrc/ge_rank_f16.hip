@@ -1,19 +1,24 @@
 // ge_rank_f16.hip -- the split-precision link-prediction sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip):
-// f16 MFMAs on pre-split candidate planes, two waves per SIMD in alternating phases.
+// f16 MFMAs on pre-split candidate planes, eight free-running waves per workgroup (two per SIMD).
 //
-// Why this shape (tools/probes/mfma_gap_probe.hip -> profiles/r03_mfma_gap_probe.txt, tools/probes/rank_phase_probe.py):
+// Why this shape (tools/probes/mfma_gap_probe.hip -> profiles/r03_mfma_gap_probe.txt, tools/probes/rank_phase_probe.py
+// and the ablations recorded in DESIGN.md section 9):
 //   * with one wave per SIMD the shadow of a v_mfma_f32_32x32x16_f16 hides four or five INDEPENDENT VALU instructions
 //     and next to nothing of the rank epilogue's compare -> scalar -> v_addc / v_writelane chains: cutting the epilogue
-//     into the gaps of the next tile's MFMAs gained nothing (measured);
-//   * eight waves that all run the MFMA loop and then all run the epilogue (one barrier domain) gain 9 %: the second
-//     wave of a SIMD must be in the OTHER phase.  So the workgroup is two groups of four waves (one per SIMD each).
-//     Each group sweeps its own 128 x 64 tiles -- staging buffers and bitmaps of its own -- and the groups run the same
-//     cycle of intervals half a cycle apart: while one issues MFMAs the other runs its epilogue, counts and stores.
-//     s_barrier counts all eight waves, so both groups execute the same number of barriers per cycle (the epilogue
-//     is cut into four pieces with a barrier behind each, a padding barrier makes the count even);
+//     into the gaps of the next tile's MFMAs gained nothing (measured).  A second wave on the SIMD hides it -- if it
+//     is in the OTHER phase;
+//   * eight waves in one barrier domain (all in the MFMA loop, then all in the epilogue) gained 9 %; two groups of
+//     four waves half a barrier cycle apart 15 %: with twelve workgroup barriers per tile the MFMA pipe still idled
+//     half the time (an ablated loop with nothing but MFMAs and barriers ran at 53 % of the pipe);
+//   * so nothing in the sweep is shared between waves any more.  Each wave owns a 64 x 32 block of the 128 x 128 tile:
+//     its candidate operands come straight from global memory (the planes are L2-resident: every CU walks the candidate
+//     tiles in the same order at the same pace) into registers in MFMA layout, three k blocks ahead; its bits go to a
+//     bitmap of its own; it counts its own rows and looks up its own known cells.  No barrier between the row
+//     block's set-up and its end: the two waves of a SIMD drift apart and one's epilogue runs under the other's MFMAs;
 //   * splitting a candidate row into fp16 planes (norm, clip scale, 2 x cvt_pkrtz per pair) was half of the sweep's
-//     VALU work and was repeated for every block of 128 test rows: it is now a pre-pass (rank_planes_launch) whose
-//     output -- `planes`, laid out per 64-candidate tile and 32-column chunk -- the sweep only copies into LDS.
+//     VALU work and was repeated for every block of 128 test rows: it is a pre-pass (rank_planes_launch) whose output
+//     -- `planes`, 1 KiB per (32 candidates, 16 columns, plane), exactly one operand fetch of one wave -- the sweep
+//     only loads.
 //
 // x * 2^8 = hi + mid with two fp16 values (round toward zero, so mid has hi's sign) is exact to 22 bits, and
 //     q . t  =  2^-16 (qh.th + qh.tm + qm.th)  +  O(2^-22) per product
@@ -28,9 +33,6 @@
 
 #include "ge_rank_dev.h"
 
-#ifndef GE_RANK_X
-#define GE_RANK_X 0      // diagnostic builds: 1 no bracket sequences, 2 no chunk loads / stores in the MFMA loop, 4 no MFMAs
-#endif
 #ifndef GE_PIPE_GRID_M
 #define GE_PIPE_GRID_M 2   // workgroups per CU (each CU holds one at a time): equal shares, two rounds
 #endif
@@ -38,16 +40,8 @@
 namespace ge {
 namespace {
 
-#ifdef GE_RANK_STAMPS   // diagnostic build only (tools/probes/rank_phase_probe.py): cycles per phase, summed over waves
-__device__ unsigned long long g_rank_stamps[16];
-#define GE_STAMP(i) do { const long long now_ = __builtin_readcyclecounter(); st_[i] += now_ - tp_; tp_ = now_; } while (0)
-#else
-#define GE_STAMP(i) do { } while (0)
-#endif
-
-constexpr int kBlk = 512;               // two groups of four waves; in a group wm = wg >> 1 (64 rows), wn = wg & 1 (32 candidates)
-constexpr int kGrp = 256;
-constexpr int kCT = 64;                 // candidates per group tile
+constexpr int kBlk = 512;               // eight waves: wm = w >> 2 (64 rows), wn = w & 3 (32 candidates of the 128-wide tile)
+constexpr int kSL = 32;                 // candidates per slice of `planes` = one wave's columns
 
 template <int I0, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -65,39 +59,36 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int KKB>
 struct HCfg {
   static constexpr int kKB = KKB;                   // k blocks of 16 (the last zero padded behind embedding_dim)
-  static constexpr int kChunks = (KKB + 1) / 2;     // staged chunks of two k blocks (32 columns)
+  static constexpr int kChunks = (KKB + 1) / 2;     // 32-column pieces of a row (the pre-pass's unit)
   static constexpr int kSA = 16 * KKB + 8;          // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
-  // barriers per tile cycle of a group: kChunks - 1 in the MFMA loop, 4 behind the epilogue pieces, 1 behind the
-  // count / next tile's first chunk; + 1 of padding when that is odd (the groups run half a cycle apart)
-  static constexpr int kCycle = ((kChunks + 4) + 1) / 2 * 2;
-  static constexpr int kPad = kCycle - (kChunks + 4);
-  static_assert(KKB >= 4 && KKB <= 13, "embedding_dim 56 ... 208 (LDS: Q planes + two chunk buffers per group)");
+  static_assert(KKB >= 4 && KKB <= 13, "embedding_dim 56 ... 208 (LDS: the Q planes)");
 };
-constexpr int kSB = 32 + 8;             // halves per candidate chunk row in LDS
 constexpr float kQScale = 256.f;        // both operands: |q|, |t * clip| <= max_norm^2 resp. max_norm sqrt(d/2)
-constexpr int kChunkHalves = 2 * kCT * 32;   // one chunk of a 64-candidate tile in `planes`: [plane][row][32 columns]
+constexpr int kOpHalves = kSL * 16;     // one operand fetch of one wave in `planes`: [32 candidates][16 columns], 1 KiB
+constexpr int kAhead = 3;               // k blocks between a candidate operand's request and its first MFMA
 
 struct HLds {
   _Float16* Ah;    // [kRB][kSA] high halves of Q * 2^8 ...
   _Float16* Am;    //   ... and the remainders (Q * 2^8 = Ah + Am to 22 bits)
-  _Float16* Bp;    // this group's [2 buffers][2 planes][kCT][kSB] candidate chunk: high halves | remainders
   float* sA;       // [kRB] 2^-16 (NaN: bad id / beyond B)
   float* eT;       // [kRB] loss of the true candidate
   float2* lohi;    // [kRB] raw-score bracket of the true candidate
-  unsigned* bm;    // this group's [kRB][2] `pops before` bits of its current tile
+  unsigned* bm;    // this wave's [64] rows x 32 `pops before` bits of its current block
   int* skip;       // [kRB] known-true candidates ranked before the target
+  int* extra;      // [kRB] candidates inside the bracket that the exact comparison put before the target
   int* tI;         // [kRB] entity id of the true candidate (-1 beyond B)
   int* tP;         // [kRB] its position among the candidates (-1: not a candidate)
+  int* next;       // [4] per candidate slice wn: the next (tile, row half) block of the sweep not yet taken by a wave
 };
 
 template <int KKB>
 constexpr size_t h_lds_bytes() {
-  return sizeof(_Float16) * ((size_t)2 * kRB * HCfg<KKB>::kSA + 2 * 2 * 2 * kCT * kSB) + sizeof(float) * 2 * kRB +
-         sizeof(float2) * kRB + sizeof(unsigned) * 2 * kRB * 2 + sizeof(int) * 3 * kRB;
+  return sizeof(_Float16) * ((size_t)2 * kRB * HCfg<KKB>::kSA) + sizeof(float) * 2 * kRB + sizeof(float2) * kRB +
+         sizeof(unsigned) * 8 * 64 + sizeof(int) * (4 * kRB + 4);
 }
 
-struct HOps { h8 ah[2], am[2], bh, bm; };           // one k block of this wave's 64 x 32 block
-struct HL { h8 hi, mid; };                           // this thread's 16 + 16 bytes of a staged chunk
+struct HA { h8 ah[2], am[2]; };          // the Q operands of one k block of this wave's 64 rows
+struct HB { h8 bh, bm; };                // the candidate operands of one k block of this wave's 32 columns
 
 __device__ __forceinline__ void h_split(float x0, float x1, h2& hi, h2& mid) {
   typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -132,86 +123,63 @@ __device__ __forceinline__ void bracket_item(float x, float2 br, int& M, unsigne
       : "vcc");
 }
 
-// chunk c of a tile of `planes` -> registers; src = the thread's 16 bytes of the tile's chunk 0, high plane
-__device__ __forceinline__ void h_load(HL& L, const _Float16* __restrict__ src, int c) {
-  L.hi = *reinterpret_cast<const h8*>(src + c * kChunkHalves);
-  L.mid = *reinterpret_cast<const h8*>(src + c * kChunkHalves + kCT * 32);
-}
-__device__ __forceinline__ void h_write(const HLds& lds, const HL& L, int srow, int qt, int buf) {
-  *reinterpret_cast<h8*>(lds.Bp + ((buf * 2 + 0) * kCT + srow) * kSB + qt * 8) = L.hi;
-  *reinterpret_cast<h8*>(lds.Bp + ((buf * 2 + 1) * kCT + srow) * kSB + qt * 8) = L.mid;
+// the candidate operands of k block kb; src = this lane's 16 bytes of the slice's k block 0, high plane
+__device__ __forceinline__ void h_loadB(HB& b, const _Float16* __restrict__ src, int kb) {
+  b.bh = *reinterpret_cast<const h8*>(src + kb * 2 * kOpHalves);
+  b.bm = *reinterpret_cast<const h8*>(src + kb * 2 * kOpHalves + kOpHalves);
 }
 
-// piece i (0..5) of the operands of k block `kb`, in the order the MFMAs of that k block first need them -- bh ah0 ah1
-// bm am0 am1 -- so that every piece is requested five or six MFMAs (>= 160 cycles) before its first use
+// piece i (0..3) of the Q operands of k block `kb`, in the order the MFMAs of that k block first need them: ah0 ah1 am0 am1
 template <int KKB>
-__device__ __forceinline__ void h_ops_piece(HOps& o, const HLds& lds, int wm, int wn, int li, int lh, int kb, int i) {
+__device__ __forceinline__ void h_opsA(HA& o, const HLds& lds, int wm, int li, int lh, int kb, int i) {
   constexpr int kSA = HCfg<KKB>::kSA;
-  if (i == 0 || i == 3) {
-    const int buf = (kb >> 1) & 1, within = kb & 1, plane = i == 3;
-    const _Float16* bp = lds.Bp + ((buf * 2 + plane) * kCT + wn * 32 + li) * kSB + within * 16 + lh * 8;
-    if (plane) o.bm = *reinterpret_cast<const h8*>(bp); else o.bh = *reinterpret_cast<const h8*>(bp);
-  } else {
-    const int tm = (i == 2 || i == 5), mid = i >= 4;
-    const _Float16* ap = (mid ? lds.Am : lds.Ah) + (wm * 64 + tm * 32 + li) * kSA + kb * 16 + lh * 8;
-    if (mid) o.am[tm] = *reinterpret_cast<const h8*>(ap); else o.ah[tm] = *reinterpret_cast<const h8*>(ap);
-  }
+  const int tm = i & 1, mid = i >> 1;
+  const _Float16* ap = (mid ? lds.Am : lds.Ah) + (wm * 64 + tm * 32 + li) * kSA + kb * 16 + lh * 8;
+  if (mid) o.am[tm] = *reinterpret_cast<const h8*>(ap); else o.ah[tm] = *reinterpret_cast<const h8*>(ap);
 }
 
-// Register slot schedule of the staged chunks.  Chunk c of a tile lives in L[c & 1] from its request to its store into
-// LDS buffer c & 1.  Slot j = -1 ... kChunks - 2 is the moment L[(j + 1) & 1] has just been stored (chunk j + 1; j = -1:
-// chunk 0, stored behind the previous tile's count): it is refilled at once with chunk j + 3 of the same tile or, past
-// the tile's end, with the next tile's chunk of that parity -- two chunks (24 MFMAs) ahead of its own store.
-template <int KKB, int J>
-__device__ __forceinline__ void h_refill(HL (&L)[2], const _Float16* __restrict__ cur, const _Float16* __restrict__ nxt) {
-  constexpr int i = J + 3;
-  if constexpr (i < HCfg<KKB>::kChunks) h_load(L[(J + 1) & 1], cur, i);
-  else h_load(L[(J + 1) & 1], nxt, (J + 1) & 1);
-}
-
-// The MFMA loop of one 128 x 64 tile: chunk 0 is in LDS buffer 0 (behind a barrier), chunk 1 in L[1], chunk 2 (or the
-// next tile's chunk 0) on its way into L[0].  kChunks - 1 barriers.  On exit L[0] / L[1] hold (or await) the NEXT
-// tile's chunks 0 / 1.
+// The MFMA loop of one 64 x 32 block.  B[0 .. kAhead - 1] hold the candidate operands of k blocks 0 .. kAhead - 1 of the
+// slice `cur` on entry and of the slice `nxt` on exit (a ring of kAhead + 1 register sets; a k block's operands are
+// requested kAhead k blocks -- 18 MFMAs -- before its first MFMA, across the block boundary too).  No barrier.
 template <int KKB>
 __device__ __forceinline__ void h_mfma_loop(const HLds& lds, const _Float16* __restrict__ cur, const _Float16* __restrict__ nxt,
-                                            HL (&L)[2], f32x16 (&acc)[2], int srow, int qt, int wm, int wn, int li, int lh) {
-  constexpr int kKB = KKB, kChunks = HCfg<KKB>::kChunks;
+                                            HB (&B)[kAhead + 1], f32x16 (&acc)[2], int wm, int li, int lh) {
+  constexpr int kKB = KKB, kR = kAhead + 1;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[a][q] = 0.f;
-  HOps ops[2];
+  HA ops[2];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) h_ops_piece<KKB>(ops[0], lds, wm, wn, li, lh, 0, i);
+  for (int i = 0; i < 4; ++i) h_opsA<KKB>(ops[0], lds, wm, li, lh, 0, i);
   static_for<0, kKB>([&](auto kbc) {
-    constexpr int kb = decltype(kbc)::value, qc = kb >> 1, within = kb & 1;
-    constexpr bool last_of_chunk = within == 1 || kb == kKB - 1;
-    if constexpr (last_of_chunk && qc + 1 < kChunks) __syncthreads();   // chunk qc+1 is in LDS; chunk qc-1's buffer is free
-    HOps& cur_ops = ops[kb & 1];
-    HOps& nxt_ops = ops[(kb + 1) & 1];
+    constexpr int kb = decltype(kbc)::value;
+    HA& ca = ops[kb & 1];
+    HA& na = ops[(kb + 1) & 1];
+    HB& cb = B[kb % kR];
     static_for<0, 6>([&](auto pc) {
       constexpr int p = decltype(pc)::value, ty = p >> 1, tm = p & 1;   // consecutive MFMAs hit different accumulators
-      const h8 a = ty == 2 ? cur_ops.am[tm] : cur_ops.ah[tm];
-      const h8 b = ty == 1 ? cur_ops.bm : cur_ops.bh;
-      if constexpr (!(GE_RANK_X & 4)) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm], 0, 0, 0);
-      else asm volatile("v_pk_add_f16 %0, %1, %2" : "+v"(acc[tm][p]) : "v"(a[0]), "v"(b[0]));   // (keeps the operand reads alive)
+      const h8 a = ty == 2 ? ca.am[tm] : ca.ah[tm];
+      const h8 b = ty == 1 ? cb.bm : cb.bh;
+      acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kb + 1 < kKB) {
-        if constexpr ((GE_RANK_X & 16) || ((GE_RANK_X & 8) && p != 0 && p != 3)) {   // diagnostic: operands not re-read
-          if constexpr (p == 0) nxt_ops.bh = cur_ops.bh; else if constexpr (p == 3) nxt_ops.bm = cur_ops.bm;
-          else if constexpr (p == 1) nxt_ops.ah[0] = cur_ops.ah[0]; else if constexpr (p == 2) nxt_ops.ah[1] = cur_ops.ah[1];
-          else if constexpr (p == 4) nxt_ops.am[0] = cur_ops.am[0]; else nxt_ops.am[1] = cur_ops.am[1];
-        } else {
-          h_ops_piece<KKB>(nxt_ops, lds, wm, wn, li, lh, kb + 1, p);
-        }
-      }
-      if constexpr (within == 0 && qc + 1 < kChunks && !(GE_RANK_X & 2)) {   // first k block of a chunk: store chunk qc+1, refill its slot
-        if constexpr (p == 2) h_write(lds, L[(qc + 1) & 1], srow, qt, (qc + 1) & 1);
-        if constexpr (p == 3) h_refill<KKB, qc>(L, cur, nxt);
+      if constexpr (p < 4) {
+        if constexpr (kb + 1 < kKB) h_opsA<KKB>(na, lds, wm, li, lh, kb + 1, p);
+      } else if constexpr (p == 4) {                              // the ring slot of k block kb - 1 is free: k block kb + kAhead
+        constexpr int kn = kb + kAhead;
+        if constexpr (kn < kKB) h_loadB(B[kn % kR], cur, kn);
+        else h_loadB(B[kn % kR], nxt, kn - kKB);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
   });
+  // the next block's k blocks 0 .. kAhead - 1 sit in ring slots (kKB + j) % kR: move them to slots j (register renaming
+  // at the loop's back edge; a few v_mov at most)
+  HB t[kAhead];
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) t[j] = B[(kKB + j) % kR];
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) B[j] = t[j];
 }
 
 // MODE 0: ranks.  1: ranks, every loss computed exactly and stored too (tests).  2: no ranking at all -- the sweep
@@ -225,38 +193,33 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags,
     const int32_t* __restrict__ pos_of, const _Float16* __restrict__ planes) {
   constexpr bool SCORES = MODE == 1;
-  constexpr int kChunks = HCfg<KKB>::kChunks, kSA = HCfg<KKB>::kSA, kCycle = HCfg<KKB>::kCycle;
-  constexpr int64_t kTileHalves = (int64_t)kChunks * kChunkHalves;
+  constexpr int kSA = HCfg<KKB>::kSA;
+  constexpr int64_t kSliceHalves = (int64_t)KKB * 2 * kOpHalves;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = w >> 2, wg = w & 3, wm = wg >> 1, wn = wg & 1;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 2, wn = w & 3;
   const int li = lane & 31, lh = lane >> 5;
-  const int tg = t & (kGrp - 1), srow = tg >> 2, qt = tg & 3;    // this group's staging: row of the 64-candidate tile, quarter
-  const int n_t64 = 2 * n_ct;                                    // tiles in `planes` (rows behind K: NaN)
+  const int qt = t & 3;
+  const int n_sl = 4 * n_ct;                                     // slices in `planes` (rows behind K: NaN)
   HLds lds;
   lds.Ah = reinterpret_cast<_Float16*>(smem);
   lds.Am = lds.Ah + kRB * kSA;
-  _Float16* bp0 = lds.Am + kRB * kSA;
-  lds.Bp = bp0 + g * (2 * 2 * kCT * kSB);
-  lds.sA = reinterpret_cast<float*>(bp0 + 2 * 2 * 2 * kCT * kSB);
+  lds.sA = reinterpret_cast<float*>(lds.Am + kRB * kSA);
   lds.eT = lds.sA + kRB;
   lds.lohi = reinterpret_cast<float2*>(lds.eT + kRB);             // an even number of floats in: 8-byte aligned
-  unsigned* bm0 = reinterpret_cast<unsigned*>(lds.lohi + kRB);
-  lds.bm = bm0 + g * (kRB * 2);
-  lds.skip = reinterpret_cast<int*>(bm0 + 2 * kRB * 2);
-  lds.tI = lds.skip + kRB;
+  lds.bm = reinterpret_cast<unsigned*>(lds.lohi + kRB) + w * 64;
+  lds.skip = reinterpret_cast<int*>(reinterpret_cast<unsigned*>(lds.lohi + kRB) + 8 * 64);
+  lds.extra = lds.skip + kRB;
+  lds.tI = lds.extra + kRB;
   lds.tP = lds.tI + kRB;
+  lds.next = lds.tP + kRB;
   const int k = d >> 1;
-#ifdef GE_RANK_STAMPS
-  long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = 0;
-#endif
 
   // This workgroup's share of the (row block, 128-candidate tile) list, row-block major -- walked so that every
   // workgroup of the chip starts at candidate tile 0 and sweeps upwards at the same pace: the share's FIRST row block
   // (entered at some tile ct_a > 0) is taken last.  The CUs of an XCD then read the same tiles of `planes` within a
   // few tiles of each other and the XCD's 4 MiB L2 serves all but the first of them; walked in list order the 32 CUs
   // sat at 32 different places of the candidate ring, the planes (13 MB) streamed through every L2 and 80 % of the
-  // reads missed it (TCC_HIT / TCC_MISS, profiles/r03_rank_profile.txt): 3.7 TB/s of Infinity-Cache reads with 32 KB
-  // in flight per CU was what bounded the sweep.
+  // reads missed it (TCC_HIT / TCC_MISS: 20 % -> 93 % hits).
   const int64_t share0 = n_tiles * blockIdx.x / gridDim.x, share1 = n_tiles * (blockIdx.x + 1) / gridDim.x;
   const int64_t first_end = min(share1, (share0 / n_ct + 1) * n_ct);
   for (int pass = 0; pass < 2; ++pass) {
@@ -280,15 +243,29 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       const bool bad = fid < 0 || fid >= N || rid < 0 || rid >= N;
       const float* frow = table + (int64_t)(bad ? 0 : fid) * d;
       const float* rrow = table + (int64_t)(bad ? 0 : rid) * d;
+      // The thread's pieces of both rows (float4 j = qt, qt + 4, ... of each half) are requested together and kept: loaded
+      // pass by pass inside the loops the staging took one memory latency per iteration, 14 of them, and the set-up of
+      // a row block cost as much as sixteen candidate tiles (measured).  Requests are clamped into the row.
+      constexpr int kNIt = (2 * KKB + 3) / 4;                    // k / 4 = embedding_dim / 8 <= 2 KKB float4 per half-row
+      const int nj = k >> 2;
+      float4 fre[kNIt], fim[kNIt], rre[kNIt], rim[kNIt];
+#pragma unroll
+      for (int i = 0; i < kNIt; ++i) {
+        const int jc = min(qt + 4 * i, nj - 1);
+        fre[i] = *reinterpret_cast<const float4*>(frow + 4 * jc); fim[i] = *reinterpret_cast<const float4*>(frow + k + 4 * jc);
+        rre[i] = *reinterpret_cast<const float4*>(rrow + 4 * jc); rim[i] = *reinterpret_cast<const float4*>(rrow + k + 4 * jc);
+      }
       float ssf = 0.f, ssr = 0.f;
       // spectral HolE (ge_complex_dev.h): Hermitian weight 2 on every bin but element 0, which packs the two REAL
       // bins X_0 | X_k; norms and score carry the Parseval factor 1/d
-      for (int j = qt; j < (k >> 2); j += 4) {                   // pass 1: the two clip norms
-        const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
-        const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
-        const float w0 = (spec && j != 0) ? 2.f : 1.f, w1 = spec ? 2.f : 1.f;     // element 0 of the row / the others
-        ssf += w0 * (fre.x * fre.x + fim.x * fim.x) + w1 * (fre.y * fre.y + fre.z * fre.z + fre.w * fre.w + fim.y * fim.y + fim.z * fim.z + fim.w * fim.w);
-        ssr += w0 * (rre.x * rre.x + rim.x * rim.x) + w1 * (rre.y * rre.y + rre.z * rre.z + rre.w * rre.w + rim.y * rim.y + rim.z * rim.z + rim.w * rim.w);
+#pragma unroll
+      for (int i = 0; i < kNIt; ++i) {                           // pass 1: the two clip norms
+        const int j = qt + 4 * i;
+        if (j < nj) {
+          const float w0 = (spec && j != 0) ? 2.f : 1.f, w1 = spec ? 2.f : 1.f;   // element 0 of the row / the others
+          ssf += w0 * (fre[i].x * fre[i].x + fim[i].x * fim[i].x) + w1 * (fre[i].y * fre[i].y + fre[i].z * fre[i].z + fre[i].w * fre[i].w + fim[i].y * fim[i].y + fim[i].z * fim[i].z + fim[i].w * fim[i].w);
+          ssr += w0 * (rre[i].x * rre[i].x + rim[i].x * rim[i].x) + w1 * (rre[i].y * rre[i].y + rre[i].z * rre[i].z + rre[i].w * rre[i].w + rim[i].y * rim[i].y + rim[i].z * rim[i].z + rim[i].w * rim[i].w);
+        }
       }
       ssf += __shfl_xor(ssf, 1, kWave); ssf += __shfl_xor(ssf, 2, kWave);
       ssr += __shfl_xor(ssr, 1, kWave); ssr += __shfl_xor(ssr, 2, kWave);
@@ -301,11 +278,12 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d * kQScale;
       _Float16* ah = lds.Ah + qrow * kSA;
       _Float16* am = lds.Am + qrow * kSA;
-      for (int j = qt; j < (k >> 2); j += 4) {                   // pass 2: q * sa * 2^8 -> high halves and remainders
-        const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
-        const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
-        const float fr[4] = {fre.x, fre.y, fre.z, fre.w}, fi[4] = {fim.x, fim.y, fim.z, fim.w};
-        const float rr[4] = {rre.x, rre.y, rre.z, rre.w}, ri[4] = {rim.x, rim.y, rim.z, rim.w};
+#pragma unroll
+      for (int it = 0; it < kNIt; ++it) {                        // pass 2: q * sa * 2^8 -> high halves and remainders
+        const int j = qt + 4 * it;
+        if (j >= nj) continue;
+        const float fr[4] = {fre[it].x, fre[it].y, fre[it].z, fre[it].w}, fi[4] = {fim[it].x, fim[it].y, fim[it].z, fim[it].w};
+        const float rr[4] = {rre[it].x, rre[it].y, rre[it].z, rre[it].w}, ri[4] = {rim[it].x, rim[it].y, rim[it].z, rim[it].w};
         float qre[4], qim[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -338,16 +316,18 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         for (int c = d; c < 16 * KKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }       // k padding
         lds.sA[qrow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
         lds.skip[qrow] = 0;
+        lds.extra[qrow] = 0;
         const int32_t tid = (MODE != 2 && r < B) ? true_id[r] : -1;
         lds.tI[qrow] = tid;
         lds.tP[qrow] = (tid >= 0 && tid < N) ? pos_of[tid] : -1;
       }
+      if (t < 4) lds.next[t] = 0;
     }
     __syncthreads();
 
-    // this group's tiles: the 64-candidate halves u = 2 ct + g of the share's 128-candidate tiles
-    auto tile_src = [&](int u) -> const _Float16* {               // this thread's 16 bytes of tile u's chunk 0 (clamped)
-      return planes + (int64_t)min(u, n_t64 - 1) * kTileHalves + tg * 8;
+    // this wave's slices of `planes`: 32 candidates each, slice 4 ct + wn of the share's 128-candidate tiles
+    auto slice_src = [&](int s) -> const _Float16* {              // this lane's 16 bytes of slice s's k block 0 (clamped)
+      return planes + (int64_t)min(s, n_sl - 1) * kSliceHalves + li * 16 + lh * 8;
     };
     auto known_of = [&](int ct, int32_t& k0, int32_t& k1) {
       k0 = k1 = 0;
@@ -357,26 +337,34 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       }
     };
     f32x16 acc[2];
-    HL L[2];
-    const int u0 = 2 * ct0 + g;
-    // ---- the true candidates: for each group a tile whose candidate rows are 64 of the block's true entities (both
-    // groups run it in the same phase)
+    HB Bq[kAhead + 1];
+    // The sweep's blocks of candidate slice wn -- (tile, row half) = (ct0 + (i >> 1), i & 1), i < 2 (ct1 - ct0) -- are handed
+    // out from a counter to the two waves that own the slice (w = wn and wn + 4: the two waves of one SIMD).  With a fixed
+    // row half each, the older wave of the SIMD won every issue arbitration, finished 14 tiles early and waited 11 % of
+    // the kernel at the closing barrier while its partner ran alone, MFMA loop and epilogue back to back (measured;
+    // alternating s_setprio did not change it).  A wave holds two blocks: the one it computes and the one it prefetches.
+    const int n_items = 2 * (ct1 - ct0);
+    auto take = [&]() -> int {
+      int v = 0;
+      if (lane == 0) v = atomicAdd(&lds.next[wn], 1);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    int item = take(), item_next = take();
+    const int s0 = 4 * (ct0 + (item >> 1)) + wn;
+    // ---- the true candidates: a tile whose candidate rows are the block's 128 true entities (this wave: 32 of them)
     if constexpr (MODE != 2) {
-      const int pos = lds.tP[g * kCT + srow];
+      const int pos = lds.tP[wn * 32 + li];
       const int pc = pos < 0 ? 0 : pos;
-      const _Float16* dsrc = planes + (int64_t)(pc >> 6) * kTileHalves + (pc & 63) * 32 + qt * 8;
-      h_load(L[0], dsrc, 0);
-      h_load(L[1], dsrc, 1);
-      h_write(lds, L[0], srow, qt, 0);
-      h_refill<KKB, -1>(L, dsrc, tile_src(u0));
-      __syncthreads();
-      h_mfma_loop<KKB>(lds, dsrc, tile_src(u0), L, acc, srow, qt, wm, wn, li, lh);   // leaves the first tile's chunks 0 / 1 in L
+      const _Float16* dsrc = planes + (int64_t)(pc >> 5) * kSliceHalves + (pc & 31) * 16 + lh * 8;
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], dsrc, j);
+      h_mfma_loop<KKB>(lds, dsrc, slice_src(s0), Bq, acc, wm, li, lh);   // leaves the first block's leading operands in Bq
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-          if (rl == g * kCT + wn * 32 + li) lds.eT[rl] = acc[tm][q];   // raw score, row scale still to come
+          if (rl == wn * 32 + li) lds.eT[rl] = acc[tm][q];        // raw score, row scale still to come
         }
       __syncthreads();
       if (t < kRB) {
@@ -396,70 +384,63 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         lds.eT[t] = e;
         if (true_loss && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
       }
-      // (the barrier that opens the sweep, below, publishes the brackets)
+      __syncthreads();
     } else {
-      h_load(L[0], tile_src(u0), 0);
-      h_load(L[1], tile_src(u0), 1);
-    }
-    int raw_reg = 0;
-
-    // ---- the sweep: this group's ct1 - ct0 tiles, one cycle of kCycle barriers each, group 1 half a cycle behind
-    int32_t kn0, kn1, kn0_next, kn1_next;
-    known_of(ct0, kn0_next, kn1_next);
-    h_write(lds, L[0], srow, qt, 0);
-    h_refill<KKB, -1>(L, tile_src(u0), tile_src(u0 + 2));
-    __syncthreads();
-    if (g == 1) {
 #pragma unroll
-      for (int i = 0; i < kCycle / 2; ++i) __builtin_amdgcn_s_barrier();
+      for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], slice_src(s0), j);
     }
-#ifdef GE_RANK_STAMPS
-    tp_ = __builtin_readcyclecounter();
-#endif
-    for (int ct = ct0; ct < ct1; ++ct) {
-      const int u = 2 * ct + g;
-      const int64_t col = (int64_t)u * kCT + wn * 32 + li;       // this lane's candidate
-      const _Float16* cur = tile_src(u);
-      const _Float16* nxt = tile_src(u + 2);
-      h_mfma_loop<KKB>(lds, cur, nxt, L, acc, srow, qt, wm, wn, li, lh);
-      // The brackets of this lane's 32 rows, requested together (the operand registers of the MFMA loop are free now):
-      // read score by score -- a wait on the LDS queue, which the other group's operand reads keep busy, in front of
-      // every compare sequence -- the epilogue took 200 cycles per score (measured, tools/probes/rank_phase_probe.py).
+    int raw_reg[2][2] = {{0, 0}, {0, 0}};                         // lane r < 32: bits counted for row half*64 + tm*32 + r
+
+    // ---- the sweep: no barrier until the row block is done
+    int32_t kn0, kn1, kn0_next, kn1_next;
+    known_of(ct0 + (item >> 1), kn0_next, kn1_next);
+    while (item < n_items) {
+      const int ct = ct0 + (item >> 1), wmi = item & 1;
+      const int s = 4 * ct + wn, s_next = 4 * (ct0 + (item_next >> 1)) + wn;
+      const int64_t col = (int64_t)s * kSL + li;                 // this lane's candidate
+      // (the next block's known-cell range is requested BEFORE the MFMA loop: it is a scalar load, and the wait in front of
+      // the epilogue -- for the brackets -- waits for everything on that counter)
+      kn0 = kn0_next; kn1 = kn1_next;
+      known_of(ct0 + (item_next >> 1), kn0_next, kn1_next);
+      h_mfma_loop<KKB>(lds, slice_src(s), slice_src(s_next), Bq, acc, wmi, li, lh);
+      item = item_next;
+      item_next = take();
+      // the brackets of this lane's 32 rows, requested together (read score by score -- a wait on the LDS queue in front
+      // of every compare sequence -- the epilogue took 200 cycles per score; held in registers across the MFMA loop
+      // they are spilled)
       float2 br[2][16];
       if constexpr (MODE == 0) {
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) br[tm][q] = lds.lohi[wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh];
+          for (int q = 0; q < 16; ++q) br[tm][q] = lds.lohi[wmi * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh];
       }
-      GE_STAMP(0);
-      kn0 = kn0_next; kn1 = kn1_next;
-      known_of(ct + 1, kn0_next, kn1_next);
-      // epilogue in four pieces (tm, half of the accumulator registers), a barrier behind each: C layout of the
-      // 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  A candidate beyond K or with a bad id
-      // has NaN planes, a row beyond B a NaN bracket: no bit is set.
-      int M = 0;                                                 // lane r: the 32 column bits of row r of the 32 x 32 block
-      unsigned I = 0;                                            // per-lane bitmap of "inside the bracket"
-      int32_t c0 = -1;
-      if constexpr (SCORES) c0 = col < K ? cand[col] : -1;
-      (void)M; (void)I; (void)c0;
-      static_for<0, 4>([&](auto ec) {
-        constexpr int piece = decltype(ec)::value, tm = piece >> 1, q0 = (piece & 1) * 8;
-        unsigned* mrow = lds.bm + (wm * 64 + tm * 32) * 2 + wn;
-        (void)mrow;
-        if constexpr (MODE == 2) {                               // scores only: 32 consecutive floats of a row per half-wave
+      // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  A candidate
+      // beyond K or with a bad id has NaN planes, a row beyond B a NaN bracket: no bit is set.
+      if constexpr (MODE == 2) {                                 // scores only: 32 consecutive floats of a row per half-wave
 #pragma unroll
-          for (int q = q0; q < q0 + 8; ++q) {
-            const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rl = wmi * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
             const int64_t row = m0 + rl;
             float v = acc[tm][q] * lds.sA[rl];
             if (sweep_flags & 1) v = rank_sigmoid(v);            // 4 VALU, within 3e-7 of expf's
             if (row < B && col < K) scores_out[row * K + col] = v;
           }
-        } else if constexpr (SCORES) {                           // tests: every loss exactly, and stored
-          static_for<q0, q0 + 8>([&](auto qc) {
+        continue;
+      }
+      int32_t c0 = -1;
+      if constexpr (SCORES) c0 = col < K ? cand[col] : -1;
+      (void)c0;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        int M = 0;                                               // lane r: the 32 column bits of row r of the 32 x 32 block
+        unsigned* mrow = lds.bm + tm * 32;
+        if constexpr (SCORES) {                                  // tests: every loss exactly, and stored
+          static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
-            const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
+            const int rl = wmi * 64 + tm * 32 + R32 + 4 * lh;
             const float et = lds.eT[rl];
             const float e0 = rank_sigmoid(acc[tm][q] * lds.sA[rl]);
             const unsigned long long mk = __ballot(e0 < et) | __ballot(e0 == et && c0 < lds.tI[rl]);
@@ -467,96 +448,81 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
             set_lane<R32>(M, (unsigned)mk);                      // (mk comes out of a scalar OR: no VALU -> VALU SGPR hazard)
             set_lane<R32 + 4>(M, (unsigned)(mk >> 32));
           });
-          if constexpr (piece & 1) {
-            if (lane < 32) mrow[lane * 2] = (unsigned)M;
-            M = 0;
-          }
+          raw_reg[0][tm] += wmi ? 0 : __popc((unsigned)M);
+          raw_reg[1][tm] += wmi ? __popc((unsigned)M) : 0;
+          if (lane < 32) mrow[lane] = (unsigned)M;
         } else {
           // Per score: "x < lo" (the bit, as a wave mask -> two v_writelane) and "x <= hi"; the scores inside the bracket
           // (le and not lt: one scalar and-not) are shifted into a per-lane bitmap (one v_addc): bracket_item.  Longer
           // scalar chains on compare results (compare / select / or per score) stall the wave: measured.
-          static_for<q0, q0 + 8>([&](auto qc) {
+          unsigned I = 0;                                        // per-lane bitmap of "inside the bracket"
+          static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
-            if constexpr ((GE_RANK_X & 32) && (q & 7)) return;   // diagnostic: one score in eight
-            if constexpr (!(GE_RANK_X & 1)) bracket_item<R32>(acc[tm][q], br[tm][q], M, I);   // (the planes carry the clip scale)
-            else { I += acc[tm][q] < br[tm][q].x ? 1u : 0u; M += acc[tm][q] <= br[tm][q].y ? 1 : 0; }
+            bracket_item<R32>(acc[tm][q], br[tm][q], M, I);      // (the planes carry the clip scale)
           });
-          if constexpr (piece & 1) {
-            if (lane < 32) mrow[lane * 2] = (unsigned)M;
-            if (I) {                                             // lanes owning a score inside a bracket: the exact
-              static_for<0, 4>([&](auto gc) {                    // comparison, bit set in LDS; 4 scores per outer test
-                constexpr int g4 = decltype(gc)::value;
-                if (I & (0xf000u >> (4 * g4))) {
-                  static_for<0, 4>([&](auto kc) {
-                    constexpr int q = 4 * g4 + decltype(kc)::value, R32 = (q & 3) + 8 * (q >> 2);
-                    if (I & (0x8000u >> q)) {
-                      const int rl = wm * 64 + tm * 32 + R32 + 4 * lh;
-                      const float e = rank_sigmoid(acc[tm][q] * lds.sA[rl]), et = lds.eT[rl];
-                      bool before = e < et;
-                      if (e == et) before = (col < K ? cand[col] : -1) < lds.tI[rl];   // equal losses pop in id order
-                      if (before) atomicOr(mrow + (R32 + 4 * lh) * 2, 1u << li);
-                    }
-                  });
-                }
-              });
-            }
-            M = 0; I = 0;
-          }
-        }
-        __syncthreads();
-      });
-      GE_STAMP(1);
-      // the tile's bitmap is complete in LDS: rows count their bits, known cells that rank before the target are tallied
-      if constexpr (MODE != 2) {
-        if (tg < kRB) {
-          const unsigned* m = lds.bm + tg * 2;
-          raw_reg += __popc(m[0]) + __popc(m[1]);
-        }
-        if (known_off) {
-          for (int32_t e = kn0 + tg; e < kn1; e += kGrp) {
-            const unsigned rc = known_rc[e];
-            const int rl = rc >> 7, cl = rc & 127;
-            if ((cl >> 6) == g && ((lds.bm[rl * 2 + ((cl >> 5) & 1)] >> (cl & 31)) & 1u)) atomicAdd(&lds.skip[rl], 1);
+          raw_reg[0][tm] += wmi ? 0 : __popc((unsigned)M);       // (lanes 32 .. 63 of M stay 0; no dynamic register index)
+          raw_reg[1][tm] += wmi ? __popc((unsigned)M) : 0;
+          if (lane < 32) mrow[lane] = (unsigned)M;
+          if (I) {                                               // lanes owning a score inside a bracket: the exact
+            static_for<0, 4>([&](auto gc) {                      // comparison, bit set in LDS; 4 scores per outer test
+              constexpr int g4 = decltype(gc)::value;
+              if (I & (0xf000u >> (4 * g4))) {
+                static_for<0, 4>([&](auto kc) {
+                  constexpr int q = 4 * g4 + decltype(kc)::value, R32 = (q & 3) + 8 * (q >> 2);
+                  if (I & (0x8000u >> q)) {
+                    const int rl = wmi * 64 + tm * 32 + R32 + 4 * lh;
+                    const float e = rank_sigmoid(acc[tm][q] * lds.sA[rl]), et = lds.eT[rl];
+                    bool before = e < et;
+                    if (e == et) before = (col < K ? cand[col] : -1) < lds.tI[rl];   // equal losses pop in id order
+                    if (before) { atomicOr(mrow + R32 + 4 * lh, 1u << li); atomicAdd(&lds.extra[rl], 1); }
+                  }
+                });
+              }
+            });
           }
         }
       }
-      // the next tile's chunk 0 (every wave of the group has left this tile's MFMA loop: four barriers ago)
-      h_write(lds, L[0], srow, qt, 0);
-      h_refill<KKB, -1>(L, nxt, tile_src(u + 4));
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < HCfg<KKB>::kPad; ++i) __builtin_amdgcn_s_barrier();
-      GE_STAMP(2);
-    }
-    if (g == 0) {
-#pragma unroll
-      for (int i = 0; i < kCycle / 2; ++i) __builtin_amdgcn_s_barrier();
+      // this wave's bitmap is complete (its own LDS writes, in order): known cells of its 64 x 32 block that rank before
+      // the target are tallied (every wave scans the tile's few cells and keeps its own)
+      if (known_off) {
+        for (int32_t e = kn0 + lane; e < kn1; e += kWave) {
+          const unsigned rc = known_rc[e];
+          const int rl = rc >> 7, cl = rc & 127;
+          if ((rl >> 6) == wmi && (cl >> 5) == wn && ((lds.bm[rl & 63] >> (cl & 31)) & 1u)) atomicAdd(&lds.skip[rl], 1);
+        }
+      }
     }
     __syncthreads();
-    if (MODE != 2 && tg < kRB && m0 + tg < B) {
-      if (raw_reg) atomicAdd(&raw_cnt[m0 + tg], raw_reg);
-      if (g == 0 && lds.skip[tg]) atomicAdd(&skip_cnt[m0 + tg], lds.skip[tg]);
+    if constexpr (MODE != 2) {
+      if (lane < 32) {
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) {
+            const int64_t row = m0 + hm * 64 + tm * 32 + lane;
+            if (row < B && raw_reg[hm][tm]) atomicAdd(&raw_cnt[row], raw_reg[hm][tm]);
+          }
+      }
+      if (t < kRB && m0 + t < B) {
+        if (lds.extra[t]) atomicAdd(&raw_cnt[m0 + t], lds.extra[t]);
+        if (lds.skip[t]) atomicAdd(&skip_cnt[m0 + t], lds.skip[t]);
+      }
     }
   }
   }
-#ifdef GE_RANK_STAMPS
-  if (lane == 0) {
-    for (int i = 0; i < 3; ++i) atomicAdd(&g_rank_stamps[i + 4 * g], (unsigned long long)st_[i]);
-    atomicAdd(&g_rank_stamps[3 + 4 * g], 1ull);
-  }
-#endif
 }
 
-// ---- the pre-pass: candidate planes.  Tile T = 64 candidates, chunk c = 32 columns:
-//   planes[((T * kChunks + c) * 2 + plane) * 64 * 32 + row * 32 + column]   fp16
-// = high halves / remainders of cand row * clip scale * 2^8 (0 behind embedding_dim; NaN for a bad id or a row behind K).
+// ---- the pre-pass: candidate planes.  Slice S = 32 candidates, k block kb = 16 columns:
+//   planes[((S * kKB + kb) * 2 + plane) * 32 * 16 + row * 16 + column]   fp16
+// = high halves / remainders of cand row * clip scale * 2^8 (0 behind embedding_dim; NaN for a bad id or a row behind K):
+// 1 KiB per (slice, k block, plane) = one operand fetch of one wave, lane (row, half) reading its 16 bytes in place.
 template <int KKB>
-__global__ __launch_bounds__(kGrp) void rank_planes_kernel(const float* __restrict__ table, int64_t N, int d,
-                                                           const int32_t* __restrict__ cand, int64_t K, float max_norm,
-                                                           int spec, _Float16* __restrict__ planes) {
+__global__ __launch_bounds__(256) void rank_planes_kernel(const float* __restrict__ table, int64_t N, int d,
+                                                          const int32_t* __restrict__ cand, int64_t K, float max_norm,
+                                                          int spec, _Float16* __restrict__ planes) {
   constexpr int kChunks = HCfg<KKB>::kChunks;
-  const int srow = threadIdx.x >> 2, qt = threadIdx.x & 3;
-  const int64_t T = blockIdx.x, pos = T * kCT + srow;
+  const int srow = threadIdx.x >> 2, qt = threadIdx.x & 3;       // 64 candidates a workgroup, four threads a row
+  const int64_t pos = (int64_t)blockIdx.x * 64 + srow;
   const int32_t id = pos < K ? cand[pos] : -1;
   const bool bad = id < 0 || id >= N;
   const float* row = table + (int64_t)(bad ? 0 : id) * d;
@@ -590,9 +556,11 @@ __global__ __launch_bounds__(kGrp) void rank_planes_kernel(const float* __restri
   // t * clip(t) * 2^8: |t clip| <= max_norm, or max_norm sqrt(d/2) for one bin of a spectral row -- no fp16 overflow
   // for max_norm <= 8 whatever the table holds
   const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
-  _Float16* dst = planes + T * (int64_t)kChunks * kChunkHalves + srow * 32 + qt * 8;
+  _Float16* dst = planes + (pos >> 5) * (int64_t)KKB * 2 * kOpHalves + (pos & 31) * 16 + (qt & 1) * 8;
 #pragma unroll
   for (int c = 0; c < kChunks; ++c) {
+    const int kb = 2 * c + (qt >> 1);                            // this thread's eight columns: half of k block kb
+    if (kb >= KKB) continue;
     const bool in = bad || c * 32 + qt * 8 < d;                  // (a bad row is NaN everywhere)
     const float x[8] = {r[c][0].x, r[c][0].y, r[c][0].z, r[c][0].w, r[c][1].x, r[c][1].y, r[c][1].z, r[c][1].w};
     h8 hi, mid;
@@ -602,8 +570,8 @@ __global__ __launch_bounds__(kGrp) void rank_planes_kernel(const float* __restri
       h_split(in ? x[2 * i] * scale : 0.f, in ? x[2 * i + 1] * scale : 0.f, a, b);
       hi[2 * i] = a.x; hi[2 * i + 1] = a.y; mid[2 * i] = b.x; mid[2 * i + 1] = b.y;
     }
-    *reinterpret_cast<h8*>(dst + c * kChunkHalves) = hi;
-    *reinterpret_cast<h8*>(dst + c * kChunkHalves + kCT * 32) = mid;
+    *reinterpret_cast<h8*>(dst + kb * 2 * kOpHalves) = hi;
+    *reinterpret_cast<h8*>(dst + kb * 2 * kOpHalves + kOpHalves) = mid;
   }
 }
 
@@ -625,7 +593,7 @@ int f16_cu_count() {
 
 inline bool f16_dim_ok(int32_t d, float max_norm) { return d % 8 == 0 && d >= 56 && d <= 208 && max_norm <= 8.f; }
 inline int64_t pos_bytes(int64_t N) { return (N * (int64_t)sizeof(int32_t) + 255) / 256 * 256; }
-inline int64_t planes_tiles(int64_t K) { return 2 * ((K + kRB - 1) / kRB); }   // 64-candidate tiles, an even number
+inline int64_t planes_slices(int64_t K) { return 4 * ((K + kRB - 1) / kRB); }   // whole 128-candidate tiles
 
 template <int KKB>
 int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
@@ -633,7 +601,7 @@ int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                    const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss, float* scores_out,
                    int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
-  if (n_ct > INT32_MAX / 4 || n_rb > INT32_MAX / 4) return GE_ENOTSUP;
+  if (n_ct > INT32_MAX / 8 || n_rb > INT32_MAX / 8) return GE_ENOTSUP;
   const int64_t n_tiles = n_rb * n_ct;
   const int64_t grid = std::min<int64_t>(n_tiles, GE_PIPE_GRID_M * (int64_t)f16_cu_count());
   const int32_t* pos_of = reinterpret_cast<const int32_t*>(planes_ws);
@@ -654,17 +622,6 @@ int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, 
 
 }  // namespace
 
-#ifdef GE_RANK_STAMPS
-extern "C" int ge_debug_rank_stamps(unsigned long long* out, int reset) {
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rank_stamps), sizeof(unsigned long long) * 16);
-  if (e == hipSuccess && reset) {
-    unsigned long long z[16] = {0};
-    e = hipMemcpyToSymbol(HIP_SYMBOL(g_rank_stamps), z, sizeof(z));
-  }
-  return (int)e;
-}
-#endif
-
 #define GE_KKB_SWITCH(d, CALL)                                                                        \
   switch (((d) + 15) / 16) {                                                                          \
     case 4: CALL(4); case 5: CALL(5); case 6: CALL(6); case 7: CALL(7); case 8: CALL(8);              \
@@ -675,8 +632,8 @@ extern "C" int ge_debug_rank_stamps(unsigned long long* out, int reset) {
 // bytes of the candidate planes of a K-candidate sweep over an N-row table (0: embedding_dim has no split-precision sweep)
 int64_t rank_planes_bytes(int64_t N, int32_t d, int64_t K) {
   if (d % 8 != 0 || d < 56 || d > 208 || N <= 0 || K <= 0) return 0;
-  const int64_t kchunks = ((d + 15) / 16 + 1) / 2;
-  return pos_bytes(N) + planes_tiles(K) * kchunks * kChunkHalves * (int64_t)sizeof(_Float16);
+  const int64_t kkb = (d + 15) / 16;
+  return pos_bytes(N) + planes_slices(K) * kkb * 2 * kOpHalves * (int64_t)sizeof(_Float16);
 }
 
 // planes_ws (rank_planes_bytes, 256-byte aligned) <- the entity -> position map, then the candidates' fp16 planes
@@ -690,10 +647,10 @@ int rank_planes_launch(const float* table, int64_t N, int32_t d, const int32_t* 
   hipError_t e = hipMemsetAsync(pos_of, 0xff, (size_t)N * sizeof(int32_t), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(rank_pos_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, cand, K, N, pos_of);
-  const int64_t n_t64 = planes_tiles(K);
-  if (n_t64 > INT32_MAX) return GE_ENOTSUP;
+  const int64_t n_blocks = planes_slices(K) / 2;                // 64 candidates a workgroup
+  if (n_blocks > INT32_MAX) return GE_ENOTSUP;
 #define GE_CALL(KKB)                                                                                                   \
-  hipLaunchKernelGGL(rank_planes_kernel<KKB>, dim3((unsigned)n_t64), dim3(kGrp), 0, st, table, N, d, cand, K, max_norm, \
+  hipLaunchKernelGGL(rank_planes_kernel<KKB>, dim3((unsigned)n_blocks), dim3(256), 0, st, table, N, d, cand, K, max_norm, \
                      spec, planes);                                                                                    \
   return launch_status()
   GE_KKB_SWITCH(d, GE_CALL)
