@@ -1,5 +1,6 @@
-// ge_rank_pipe.hip -- the link-prediction ranking sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip),
-// software-pipelined for one wave per SIMD.
+// ge_rank_pipe.hip -- the link-prediction ranking sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip) on the fp32
+// MFMA, software-pipelined for one wave per SIMD.  It serves what the split-precision sweep (ge_rank_f16.hip, tried
+// first by sweep_pipe_launch) does not: embedding_dim % 8 == 0 below 56 or above 208, and max_norm > 8.
 //
 // What the microbenchmark (tools/probes/mfma_probe.hip) says about v_mfma_f32_32x32x2_f32 on gfx950 with one
 // wave per SIMD (the Q operand fills the LDS, so a CU holds one workgroup):
@@ -24,7 +25,6 @@
 //   * model: ComplEx, or HolE on a table held in the frequency domain (same GEMM; Hermitian weights go into Q,
 //     the candidate norm is Parseval-weighted).
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 #include "ge_rank_dev.h"
@@ -59,9 +59,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct Ops { float a0[4], a1[4], b0[4], b1[4]; };   // 4 k-pairs of this wave's 64 x 64 block: 2 A and 2 B fragments
 
 struct PipeLds {
-  _Float16* Ah;    // split-precision sweep only: [kRB][kSA] high halves of Q * 2^8 ...
-  _Float16* Am;    //   ... and the remainders (Q * 2^8 = Ah + Am to 22 bits)
-  _Float16* Bp;    //   [2 buffers][2 planes][kRB][kSB] candidate chunk * 2^4, high halves | remainders
   float* A;        // [kRB][lda]  q = fixed o relation, not yet scaled by the rows' clip scales
   float* Bs;       // [2][kRB][CW+1]
   float* sA;       // [kRB] product of the fixed and relation rows' clip scales (NaN: bad id / beyond B)
@@ -222,164 +219,9 @@ __device__ __forceinline__ void pipe_tile(const float* __restrict__ table, int64
 // v_writelane_b32 with a constant lane (this clang has no builtin for it): lane `LANE` of m = the wave-uniform v.
 template <int LANE>
 __device__ __forceinline__ void set_lane(int& m, unsigned v) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(v), "n"(LANE));
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Split-precision sweep (embedding_dim 200).  The fp32 MFMA tops out at 157 TFLOP/s; v_mfma_f32_32x32x16_f16 is 16x
-// faster.  x * 2^s = hi + mid with two fp16 values (round toward zero, so mid has hi's sign) is exact to 22 bits, and
-//     q . t  =  2^-12 (qh.th + qh.tm + qm.th)  +  O(2^-22) per product
-// accumulated in fp32: three f16 MFMAs per 16-wide k block instead of eight fp32 MFMAs.  Q (pre-multiplied by the
-// rows' clip scales, so |q| <= 1, scaled 2^8) sits in LDS as two fp16 planes -- the same 103 KB as fp32; a candidate
-// row (held whole in registers a tile ahead, so its clip scale is known first: |t clip(t)| <= 1, scaled 2^8) is
-// split chunk by chunk as it is stored to LDS.  No fp16 overflow for any table.  13 k blocks of 16 for d = 200 (208
-// columns, zero padded): chunks of two k blocks, the last of one.
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-template <int D>
-struct FCfg {                           // D = embedding_dim, compiled for 64, 96, 128, 160, 192 and 200
-  static constexpr int kKB = (D + 15) / 16;       // k blocks of 16 (the last zero padded)
-  static constexpr int kChunks = (kKB + 1) / 2;   // staged chunks of two k blocks = register slots of 32 reals
-  static constexpr int kSA = 16 * kKB + 8;        // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
-  static_assert(D % 8 == 0 && D >= 64 && D <= 208, "embedding_dim of the split-precision sweep (LDS: Q planes + chunks)");
-};
-constexpr int kSB = 32 + 8;             // halves per candidate chunk row
-constexpr float kQScale = 256.f;   // both operands: |q|, |t * clip| <= 1
-
-struct F16Ops { h8 ah[2], am[2], bh[2], bm[2]; };
-
-template <int D>
-constexpr size_t f16_lds_bytes() {
-  return sizeof(_Float16) * ((size_t)2 * kRB * FCfg<D>::kSA + 2 * 2 * kRB * kSB) + sizeof(float) * 3 * kRB + sizeof(float2) * kRB +
-         sizeof(unsigned) * kRB * 4 + sizeof(int) * 2 * kRB;
-}
-
-// slot c (chunk c of the row: 32 reals, this thread's 16) -- clamped to the row, zeroed when stored
-template <int D>
-__device__ __forceinline__ void f16_fetch(const float* __restrict__ crow, int half, int c, float4 (&r)[4]) {
-#pragma unroll
-  for (int v = 0; v < 4; ++v) r[v] = *reinterpret_cast<const float4*>(crow + min(c * 32 + half * 16 + 4 * v, D - 4));
-}
-
-__device__ __forceinline__ void f16_split(float x0, float x1, float scale, h2& hi, h2& mid) {
-  x0 *= scale; x1 *= scale;
-  typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-  const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  hi = __builtin_bit_cast(h2, h);
-  const fp16x2 m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hi.x, x1 - (float)hi.y);
-  mid = __builtin_bit_cast(h2, m);
-}
-
-// half `part` (8 reals: two float4) of slot `C`, times `scale`, to the two planes of LDS buffer `buf`
-template <int D, int C>
-__device__ __forceinline__ void f16_stash(const PipeLds& lds, int srow, int half, int buf, int part, const float4 (&r)[4],
-                                          float scale) {
-  float x[8] = {r[2 * part].x, r[2 * part].y, r[2 * part].z, r[2 * part].w,
-                r[2 * part + 1].x, r[2 * part + 1].y, r[2 * part + 1].z, r[2 * part + 1].w};
-  if (C == FCfg<D>::kChunks - 1) {              // the last slot may reach past the row (d = 200: columns 200..223)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = (C * 32 + half * 16 + 8 * part + i < D) ? x[i] : 0.f;
-  }
-  h8 hi, mid;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h2 a, b;
-    f16_split(x[2 * i], x[2 * i + 1], scale, a, b);
-    hi[2 * i] = a.x; hi[2 * i + 1] = a.y; mid[2 * i] = b.x; mid[2 * i + 1] = b.y;
-  }
-  _Float16* dh = lds.Bp + ((buf * 2 + 0) * kRB + srow) * kSB + half * 16 + 8 * part;
-  _Float16* dm = lds.Bp + ((buf * 2 + 1) * kRB + srow) * kSB + half * 16 + 8 * part;
-  *reinterpret_cast<h8*>(dh) = hi;
-  *reinterpret_cast<h8*>(dm) = mid;
-}
-
-// piece i (0..7) of the operands of k block `kb`
-template <int D>
-__device__ __forceinline__ void f16_ops_piece(F16Ops& o, const PipeLds& lds, int wm, int wn, int li, int lh, int kb, int i) {
-  constexpr int kSA = FCfg<D>::kSA;
-  const int t2 = i & 1;
-  const int buf = (kb >> 1) & 1, within = kb & 1;
-  const _Float16* ap = (i & 2 ? lds.Am : lds.Ah) + (wm * 64 + t2 * 32 + li) * kSA + kb * 16 + lh * 8;
-  const _Float16* bp = lds.Bp + ((buf * 2 + ((i >> 1) & 1)) * kRB + wn * 64 + t2 * 32 + li) * kSB + within * 16 + lh * 8;
-  if (i < 4) { if (i & 2) o.am[t2] = *reinterpret_cast<const h8*>(ap); else o.ah[t2] = *reinterpret_cast<const h8*>(ap); }
-  else { if (i & 2) o.bm[t2] = *reinterpret_cast<const h8*>(bp); else o.bh[t2] = *reinterpret_cast<const h8*>(bp); }
-}
-
-// One 128 x 128 tile on the f16 planes.  R[c] holds slot c of this tile's candidate row on entry and slot c of the
-// NEXT tile's row (next_row) on exit: a slot is refilled right after it has been stored to LDS, a whole tile ahead
-// of its use.
-template <int D>
-__device__ __forceinline__ void f16_tile(const float* __restrict__ next_row, bool bad, float max_norm, int spec,
-                                         const PipeLds& lds, float4 (&R)[FCfg<D>::kChunks][4], f32x16 (&acc)[2][2]) {
-  constexpr int kFD = D, kFKB = FCfg<D>::kKB, kFChunks = FCfg<D>::kChunks;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
-  const int srow = t >> 1, half = t & 1;
-  const int li = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-  // The whole row is in registers, so its clip scale is known BEFORE anything is stored: the planes hold
-  // t * clip(t) * 2^8 (|t clip| <= max_norm, or max_norm sqrt(d/2) for one bin of a spectral row: no fp16 overflow
-  // for max_norm <= 8 whatever the table holds) and the epilogue needs no column scale.
-  f2 ss2 = {0.f, 0.f};
-  static_for<0, kFChunks>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const bool in = c * 32 + half * 16 + 4 * v + 3 < kFD;       // compile-time true except in the last slot
-      const f2 xy = in ? f2{R[c][v].x, R[c][v].y} : f2{0.f, 0.f}, zw = in ? f2{R[c][v].z, R[c][v].w} : f2{0.f, 0.f};
-      ss2 = __builtin_elementwise_fma(xy, xy, ss2);
-      ss2 = __builtin_elementwise_fma(zw, zw, ss2);
-    }
-  });
-  float ss = ss2.x + ss2.y;
-  // spectral HolE rows: |x|^2 = (2 sum - X_0^2 - X_k^2) / d; the two real bins sit at columns 0 and d/2
-  constexpr int kNy = D / 2, kNySlot = kNy / 32, kNyHalf = (kNy % 32) / 16, kNyV = (kNy % 16) / 4, kNyC = kNy % 4;
-  const float4 nyv = R[kNySlot][kNyV];
-  const float x_ny = kNyC == 0 ? nyv.x : kNyC == 1 ? nyv.y : kNyC == 2 ? nyv.z : nyv.w, x_dc = R[0][0].x;
-  float corr = (half == 0 ? x_dc * x_dc : 0.f) + (half == kNyHalf ? x_ny * x_ny : 0.f);
-  ss += __shfl_xor(ss, 1, kWave);
-  corr += __shfl_xor(corr, 1, kWave);
-  if (spec) ss = (2.f * ss - corr) / (float)D;
-  float inv;
-  const float scale = bad ? __builtin_nanf("") : clip_scale(ss, max_norm, inv) * kQScale;
-  f16_stash<D, 0>(lds, srow, half, 0, 0, R[0], scale);
-  f16_stash<D, 0>(lds, srow, half, 0, 1, R[0], scale);
-  __syncthreads();
-  // after the barrier: every wave has left the previous tile's epilogue, which reads sB (the scores-only epilogue
-  // has no barrier of its own behind those reads)
-  if (half == 0) lds.sB[srow] = bad ? __builtin_nanf("") : 1.0f;   // (the shared epilogue multiplies by it)
-  F16Ops ops[2];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) f16_ops_piece<D>(ops[0], lds, wm, wn, li, lh, 0, i);
-  static_for<0, kFKB>([&](auto kbc) {
-    constexpr int kb = decltype(kbc)::value, qc = kb >> 1, within = kb & 1;
-    constexpr bool last_of_chunk = within == 1 || kb == kFKB - 1;
-    if (last_of_chunk && qc + 1 < kFChunks) __syncthreads();      // chunk qc+1 is in LDS; chunk qc-1's buffer is free
-    F16Ops& cur = ops[kb & 1];
-    F16Ops& nxt = ops[(kb + 1) & 1];
-#pragma unroll
-    for (int p = 0; p < 12; ++p) {
-      const int ty = p >> 2, tm = (p >> 1) & 1, tn = p & 1;       // consecutive MFMAs hit different accumulators
-      const h8 a = ty == 0 ? cur.am[tm] : cur.ah[tm];
-      const h8 b = ty == 1 ? cur.bm[tn] : cur.bh[tn];
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tm][tn], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p < 8) {
-        if (kb + 1 < kFKB) f16_ops_piece<D>(nxt, lds, wm, wn, li, lh, kb + 1, p);
-      } else if (!last_of_chunk) {                                // first k block of a chunk: store chunk qc+1
-        if (p < 10 && qc + 1 < kFChunks) f16_stash<D, (qc + 1 < kFChunks ? qc + 1 : 0)>(lds, srow, half, (qc + 1) & 1, p - 8, R[qc + 1 < kFChunks ? qc + 1 : 0], scale);
-      } else {                                                    // last k block: refill the slot just stored
-        constexpr int slot = qc + 1 < kFChunks ? qc + 1 : 0;
-        R[slot][p - 8] = *reinterpret_cast<const float4*>(next_row + min(slot * 32 + half * 16 + 4 * (p - 8), kFD - 4));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  });
-  __syncthreads();                              // the bitmask / bracket arrays of the epilogue are free again
+  // (s_nop 1: v may come straight out of a VALU compare, and on gfx950 a VALU read of a VALU-written SGPR needs two wait
+  // states, which the compiler's hazard recognizer cannot insert for an instruction inside inline asm)
+  asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(v), "n"(LANE));
 }
 
 // m = 2 * m + (this lane's bit of the wave mask): one v_addc_co_u32 with the mask as carry-in
@@ -407,7 +249,7 @@ __device__ __forceinline__ void exact_masks(const PipeLds& lds, float x0, float 
 
 // MODE 0: ranks.  1: ranks, every loss computed exactly and stored too (tests).  2: no ranking at all -- the sweep
 // writes scores_out[B,K] (raw score, or its sigmoid when `sweep_flags` & 1): ge_complex_score_1vK on this pipeline.
-template <int CW, int NCH, int MODE, int FD = 0>   // FD > 0: the split-precision sweep compiled for embedding_dim FD
+template <int CW, int NCH, int MODE>
 __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
@@ -415,26 +257,14 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
     float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags) {
   constexpr bool SCORES = MODE == 1;
-  constexpr bool F16 = FD > 0;
-  constexpr int DF = F16 ? FD : 64;                               // (any valid value where the f16 code is discarded)
-  constexpr int kFD = DF, kFKB = FCfg<DF>::kKB, kFChunks = FCfg<DF>::kChunks, kSA = FCfg<DF>::kSA;
   using C = Cfg<CW>;
   constexpr int NV = C::kNV;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lda = d + 1;
   PipeLds lds;
-  if constexpr (F16) {
-    lds.Ah = reinterpret_cast<_Float16*>(smem);
-    lds.Am = lds.Ah + kRB * kSA;
-    lds.Bp = lds.Am + kRB * kSA;
-    lds.A = lds.Bs = nullptr;
-    lds.sA = reinterpret_cast<float*>(lds.Bp + 2 * 2 * kRB * kSB);
-  } else {
-    lds.Ah = lds.Am = lds.Bp = nullptr;
-    lds.A = smem;
-    lds.Bs = lds.A + kRB * lda;
-    lds.sA = lds.Bs + 2 * kRB * C::kLdb;
-  }
+  lds.A = smem;
+  lds.Bs = lds.A + kRB * lda;
+  lds.sA = lds.Bs + 2 * kRB * C::kLdb;
   lds.sB = lds.sA + kRB;
   lds.eT = lds.sB + kRB;
   lds.lohi = reinterpret_cast<float2*>(lds.eT + kRB);             // an even number of floats in: 8-byte aligned
@@ -458,71 +288,6 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     __syncthreads();                                             // the previous row block's LDS is done with
 
     // ---- Q = fixed o relation for the block's 128 rows
-    if constexpr (F16) {     // scaled by the rows' clip scales and 2^8, split into two fp16 planes (see f16_tile)
-      const int64_t r = m0 + srow;
-      int32_t fid = -1, rid = -1;
-      if (r < B) { fid = hr[2 * r]; rid = hr[2 * r + 1]; }
-      const bool bad = fid < 0 || fid >= N || rid < 0 || rid >= N;
-      const float* frow = table + (int64_t)(bad ? 0 : fid) * d;
-      const float* rrow = table + (int64_t)(bad ? 0 : rid) * d;
-      float ssf = 0.f, ssr = 0.f;
-      // spectral HolE (ge_complex_dev.h): Hermitian weight 2 on every bin but element 0, which packs the two REAL
-      // bins X_0 | X_k; norms and score carry the Parseval factor 1/d
-      for (int j = half; j < (k >> 2); j += 2) {                 // pass 1: the two clip norms
-        const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
-        const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
-        const float w0 = (spec && j != 0) ? 2.f : 1.f, w1 = spec ? 2.f : 1.f;     // element 0 of the row / the others
-        ssf += w0 * (fre.x * fre.x + fim.x * fim.x) + w1 * (fre.y * fre.y + fre.z * fre.z + fre.w * fre.w + fim.y * fim.y + fim.z * fim.z + fim.w * fim.w);
-        ssr += w0 * (rre.x * rre.x + rim.x * rim.x) + w1 * (rre.y * rre.y + rre.z * rre.z + rre.w * rre.w + rim.y * rim.y + rim.z * rim.z + rim.w * rim.w);
-      }
-      ssf += __shfl_xor(ssf, 1, kWave);
-      ssr += __shfl_xor(ssr, 1, kWave);
-      float i0, i1;
-      const float inv_d = spec ? 1.0f / (float)d : 1.0f;
-      // The planes hold q * (clip scales) * (1/d for a spectral table) * 2^8.  ComplEx: |q sa| <= 2 max_norm^2.  A spectral
-      // row's clip bounds its Parseval-weighted norm, so ONE bin may reach max_norm sqrt(d/2) and a Hermitian-weighted
-      // product d max_norm^2: the 1/d of the correlation theorem is folded in BEFORE the split (|q sa / d| <= max_norm^2),
-      // which keeps every plane entry below 2^8 * 64 for max_norm <= 8 whatever the table holds.
-      const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d;
-      _Float16* ah = lds.Ah + srow * kSA;
-      _Float16* am = lds.Am + srow * kSA;
-      for (int j = half; j < (k >> 2); j += 2) {                 // pass 2: q * sa * 2^8 -> high halves and remainders
-        const float4 fre = *reinterpret_cast<const float4*>(frow + 4 * j), fim = *reinterpret_cast<const float4*>(frow + k + 4 * j);
-        const float4 rre = *reinterpret_cast<const float4*>(rrow + 4 * j), rim = *reinterpret_cast<const float4*>(rrow + k + 4 * j);
-        const float fr[4] = {fre.x, fre.y, fre.z, fre.w}, fi[4] = {fim.x, fim.y, fim.z, fim.w};
-        const float rr[4] = {rre.x, rre.y, rre.z, rre.w}, ri[4] = {rim.x, rim.y, rim.z, rim.w};
-        float qre[4], qim[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool packed = spec && j == 0 && i == 0;
-          if (packed) {          // two independent real dimensions: products of the re slots and of the im slots
-            qre[i] = fr[i] * rr[i];
-            qim[i] = fi[i] * ri[i];
-          } else if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
-            qre[i] = fr[i] * rr[i] - fi[i] * ri[i];
-            qim[i] = fr[i] * ri[i] + fi[i] * rr[i];
-          } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
-            qre[i] = rr[i] * fr[i] + ri[i] * fi[i];
-            qim[i] = -(ri[i] * fr[i] - rr[i] * fi[i]);
-          }
-          if (spec && !packed) { qre[i] *= 2.f; qim[i] *= 2.f; }   // Hermitian weight
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-          h2 a, b;
-          f16_split(qre[i] * sa, qre[i + 1] * sa, kQScale, a, b);
-          ah[4 * j + i] = a.x; ah[4 * j + i + 1] = a.y; am[4 * j + i] = b.x; am[4 * j + i + 1] = b.y;
-          f16_split(qim[i] * sa, qim[i + 1] * sa, kQScale, a, b);
-          ah[k + 4 * j + i] = a.x; ah[k + 4 * j + i + 1] = a.y; am[k + 4 * j + i] = b.x; am[k + 4 * j + i + 1] = b.y;
-        }
-      }
-      if (half == 0) {
-        for (int c = kFD; c < 16 * kFKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }   // k padding
-        lds.sA[srow] = (bad || r >= B) ? __builtin_nanf("") : 1.0f / (kQScale * kQScale);
-        lds.skip[srow] = 0;
-        lds.tI[srow] = (MODE != 2 && r < B) ? true_id[r] : -1;
-      }
-    } else
     {   // whole k range in fp32; the clip scales stay a per-row factor
       const int64_t r = m0 + srow;
       int32_t fid = -1, rid = -1;
@@ -586,23 +351,12 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     };
     f32x16 acc[2][2];
     float4 rA[NV], rB[NV];
-    float4 R[F16 ? kFChunks : 1][4];                              // split-precision sweep: the whole candidate row, by slot
-    auto row_of = [&](int32_t id) -> const float* {               // (bad ids read row 0; their clip scale is NaN)
-      return table + (int64_t)((id < 0 || id >= N) ? 0 : id) * d;
-    };
     // ---- the true candidates: a tile whose candidate rows are this block's 128 true entities
     if constexpr (MODE != 2) {
       const int32_t tid = lds.tI[srow];
-      if constexpr (F16) {
-        const float* trow = row_of(tid);
-#pragma unroll
-        for (int c = 0; c < kFChunks; ++c) f16_fetch<DF>(trow, half, c, R[c]);
-        f16_tile<DF>(row_of(cand_of(ct0)), tid < 0 || tid >= N, max_norm, spec, lds, R, acc);   // leaves the first tile's row in R
-      } else {
-        pipe_fetch<CW>(table, N, d, tid, 0, rA);
-        pipe_fetch<CW>(table, N, d, tid, 1, rB);
-        pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, spec, lds, rA, rB, acc);
-      }
+      pipe_fetch<CW>(table, N, d, tid, 0, rA);
+      pipe_fetch<CW>(table, N, d, tid, 1, rB);
+      pipe_tile<CW, NCH>(table, N, d, lda, tid, max_norm, spec, lds, rA, rB, acc);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -639,25 +393,14 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     // candidate ids and known-cell ranges are requested one tile ahead of their use: nothing ever waits on them
     int32_t cid = cand_of(ct0), cid_next = cand_of(ct0 + 1), kn0, kn1, kn0_next, kn1_next;
     known_of(ct0, kn0_next, kn1_next);
-    if constexpr (F16) {
-      if constexpr (MODE == 2) {                                  // no diagonal tile ran: the first row is not in R yet
-        const float* crow0 = row_of(cid);
-#pragma unroll
-        for (int c = 0; c < kFChunks; ++c) f16_fetch<DF>(crow0, half, c, R[c]);
-      }
-    } else {
-      pipe_fetch<CW>(table, N, d, cid, 0, rA);
-      pipe_fetch<CW>(table, N, d, cid, 1, rB);
-    }
+    pipe_fetch<CW>(table, N, d, cid, 0, rA);
+    pipe_fetch<CW>(table, N, d, cid, 1, rB);
     for (int ct = ct0; ct < ct1; ++ct) {
       const int64_t n0 = (int64_t)ct * kRB;
-      if constexpr (F16) f16_tile<DF>(row_of(cid_next), cid < 0 || cid >= N, max_norm, spec, lds, R, acc);
-      else pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
+      pipe_tile<CW, NCH>(table, N, d, lda, cid, max_norm, spec, lds, rA, rB, acc);
       cid = cid_next; kn0 = kn0_next; kn1 = kn1_next;
-      if constexpr (!F16) {
-        pipe_fetch<CW>(table, N, d, cid, 0, rA);                 // land while the epilogue below runs
-        pipe_fetch<CW>(table, N, d, cid, 1, rB);
-      }
+      pipe_fetch<CW>(table, N, d, cid, 0, rA);                   // land while the epilogue below runs
+      pipe_fetch<CW>(table, N, d, cid, 1, rB);
       cid_next = cand_of(ct + 2);
       known_of(ct + 1, kn0_next, kn1_next);
       // epilogue: C layout of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -709,8 +452,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
           static_for<0, 16>([&](auto qc) {
             constexpr int q = decltype(qc)::value, R32 = (q & 3) + 8 * (q >> 2);
             const float2 br = lds.lohi[wm * 64 + tm * 32 + R32 + 4 * lh];
-            // (split-precision sweep: the candidate planes already carry the clip scale)
-            const float x0 = F16 ? acc[tm][0][q] : acc[tm][0][q] * sb0, x1 = F16 ? acc[tm][1][q] : acc[tm][1][q] * sb1;
+            const float x0 = acc[tm][0][q] * sb0, x1 = acc[tm][1][q] * sb1;
             const unsigned long long lt0 = __ballot(x0 < br.x), lt1 = __ballot(x1 < br.x);
             shift_in(I0, __ballot(x0 <= br.y) & ~lt0);            // one scalar and-not per score, no chain
             shift_in(I1, __ballot(x1 <= br.y) & ~lt1);
@@ -791,25 +533,6 @@ int pipe_launch_cw(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                        cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct, n_tiles, spec, sweep_flags);
     return launch_status();
   };
-  // split-precision sweep (fp16 hi/mid planes, f16 MFMA): the dims it is compiled for, ComplEx and spectral HolE tables
-  auto go16 = [&](auto kern, size_t lds16) -> int {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), lds16, st, table, N, d, hr, B, true_id, cand, K,
-                       max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss, scores_out, (int)n_ct,
-                       n_tiles, spec, sweep_flags);
-    return launch_status();
-  };
-#define GE_F16(DD)                                                                                     \
-  if (d == DD && max_norm <= 8.f) {   /* |q sa (1/d)| <= 2 max_norm^2, |t clip| <= max_norm sqrt(d/2): x 2^8 inside fp16 */ \
-    if (scores_only) return go16(rank_pipe_kernel<CW, 0, 2, DD>, f16_lds_bytes<DD>());                 \
-    if (scores_out) return go16(rank_pipe_kernel<CW, 0, 1, DD>, f16_lds_bytes<DD>());                  \
-    return go16(rank_pipe_kernel<CW, 0, 0, DD>, f16_lds_bytes<DD>());                                  \
-  }
-  if constexpr (CW == 40) { GE_F16(200) GE_F16(160) }
-  if constexpr (CW == 32) { GE_F16(64) GE_F16(128) GE_F16(96) GE_F16(192) }
-#undef GE_F16
   if (scores_only) return (CW == 40 && d == 200) ? go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 2>) : go(rank_pipe_kernel<CW, 0, 2>);
   if (scores_out) return go(rank_pipe_kernel<CW, 0, 1>);
   if (CW == 40 && d == 200) return go(rank_pipe_kernel<CW, (CW == 40 ? 5 : 0), 0>);   // the FB15k configuration, unrolled
@@ -840,7 +563,7 @@ int sweep_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* h
                       const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                       const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                       float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
-  if (!getenv("GE_RANK_F16_OLD")) {
+  {   // embedding_dim % 8 == 0 in 56 ... 208, max_norm <= 8: the split-precision sweep (ge_rank_f16.hip)
     const int rc = sweep_f16_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
                                     skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, planes_ws, st);
     if (rc != GE_ENOTSUP) return rc;

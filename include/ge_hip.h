@@ -207,8 +207,8 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * scores_out (nullable) [B,K] receives every loss -- for tests.  d must be a multiple of 8 and <= ge_rank_max_dim()
  * (the block's Q operand lives in LDS for the whole sweep), table 16-byte aligned; otherwise GE_ENOTSUP and the
  * caller falls back to ge_complex_score_1vK.
- * Arithmetic: fp32 MFMA with fp32 accumulation; for d = 64, 96, 128, 160, 192, 200 and max_norm <= 8 the operands are split into
- * fp16 high halves and remainders (22 bits each, after the clip scales, so no fp16 overflow for any table) and
+ * Arithmetic: fp32 MFMA with fp32 accumulation; for every d % 8 == 0 in 56 ... 208 and max_norm <= 8 the operands are split
+ * into fp16 high halves and remainders (22 bits each, after the clip scales, so no fp16 overflow for any table) and
  * multiplied by three f16 MFMAs with fp32 accumulation -- losses within 1e-7 of the fp64 restatement either way
  * (ge_complex_score_1vK takes the same route for large sweeps at those dims). */
 int ge_rank_max_dim(void);
@@ -233,7 +233,8 @@ int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int
  *   ge_rank_planes_bytes   bytes of the buffer (0: this embedding_dim has no such sweep -- pass planes = NULL)
  *   ge_rank_planes         fills it (256-byte aligned); valid until the table, cand or max_norm change
  *   ge_rank_1vK_planes     ge_rank_1vK with the buffer (NULL: as ge_rank_1vK).  cand_is_head does not enter the planes.
- * A true_id that is not in `cand` has no rank: n_before = n_known_before = 0, true_loss NaN (all kernels). */
+ * The contract says true_id[i] is in `cand`; where it is not, the split-precision sweep reports no rank (n_before =
+ * n_known_before = 0, true_loss NaN) while the fp32 kernels rank the entity against the candidates all the same. */
 int64_t ge_rank_planes_bytes(int64_t N, int32_t d, int64_t K);
 int ge_rank_planes(const float* table, int64_t N, int32_t d, const int32_t* cand, int64_t K, float max_norm, int model,
                    void* planes, void* stream);

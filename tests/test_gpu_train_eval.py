@@ -52,12 +52,14 @@ def _all_scores(emb, test, cand, side, fused):
     return H.score_candidates(emb, hr, c, cand_is_head=(side == "head")).cpu().numpy()
 
 
-@pytest.mark.parametrize("fused,d", [(True, 64), (False, 64), (True, 96), (True, 128), (True, 160), (True, 192), (True, 200), (True, 56), (True, 120), (True, 48), (True, 40)])
+@pytest.mark.parametrize("fused,d", [(True, 64), (False, 64), (True, 96), (True, 128), (True, 160), (True, 192), (True, 200), (True, 56),
+                                     (True, 72), (True, 104), (True, 120), (True, 136), (True, 176), (True, 208), (True, 216), (True, 48), (True, 40)])
 def test_gpu_ranks_equal_reference_heap_semantics(fused, d):
     """Raw and filtered ranks (counted in the GEMM epilogue when fused, with tensor ops on the stored scores
     otherwise) equal the reference's heap (holE.py:427-472, oracle restatement) fed with the same losses,
-    exact ties included; the losses themselves are within 1e-5 of the fp64 oracle.  embedding_dim 64 / 96 / 128 / 160 / 192 / 200 run
-    the split-precision sweep, 120 / 48 / 40 the fp32 pipeline with chunk widths 40 / 24 / 40, 56 the generic kernel."""
+    exact ties included; the losses themselves are within 1e-5 of the fp64 oracle.  embedding_dim 56 ... 208 (every number
+    of 16-column k blocks from 4 to 13, full and ragged last block) run the split-precision sweep, 216 / 48 / 40 the fp32
+    pipeline with chunk widths 24 / 24 / 40."""
     from graphembeddings_amd import evaluate as E
     rng = np.random.default_rng(1)
     R, N = 5, 405
@@ -104,12 +106,52 @@ def test_gpu_ranks_equal_reference_heap_semantics(fused, d):
             assert [raw[i]] == rp and [fil[i]] == fp, (side, i, raw[i], rp, fil[i], fp)
 
 
+@pytest.mark.parametrize("d,model", [(200, "complex"), (104, "hole_spectral"), (40, "complex")])
+def test_rank_planes_built_once_equal_planes_built_per_call(d, model):
+    """ge_rank_planes / ge_rank_1vK_planes: the candidates' fp16 planes built once (H.RankPlanes) give the counts and losses
+    of the call that builds them itself, tails and heads, with a candidate list that is not a multiple of 128, bad ids in
+    it, and true ids that are not candidates (no rank: counts 0, loss NaN).  d = 40 has no split-precision sweep: the
+    planes object is empty and ignored."""
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(11)
+    N, B = 700, 300
+    table = (rng.standard_normal((N, d)) * 0.3).astype(np.float32)
+    emb = torch.as_tensor(table).cuda()
+    if model == "hole_spectral":
+        emb = H.hole_to_spectral(emb)
+    cand_np = rng.permutation(np.arange(10, N - 40))[:517].astype(np.int32)     # 517 candidates: five 128-tiles, the last ragged
+    cand_np[5] = -3; cand_np[400] = N + 7                                        # bad ids: never rank before anything
+    cand = torch.as_tensor(cand_np).cuda()
+    hr = torch.as_tensor(np.stack([rng.integers(0, N, B), rng.integers(0, 10, B)], 1).astype(np.int32)).cuda()
+    tid_np = rng.choice(cand_np[(cand_np >= 0) & (cand_np < N)][:500], B).astype(np.int32)
+    tid_np[7] = N - 3; tid_np[100] = N - 5                                      # not in the candidate list
+    tid = torch.as_tensor(tid_np).cuda()
+    planes = H.RankPlanes(emb, cand, model=model)
+    assert (planes.buffer is None) == (d == 40)
+    for head in (False, True):
+        a = H.rank_candidates(emb, hr, tid, cand, cand_is_head=head, return_true_loss=True, model=model)
+        b = H.rank_candidates(emb, hr, tid, cand, cand_is_head=head, return_true_loss=True, model=model, planes=planes)
+        for x, y in zip(a, b):
+            assert torch.equal(torch.nan_to_num(x.float(), nan=-1.0), torch.nan_to_num(y.float(), nan=-1.0))
+        nb, nk, tl = b
+        if d != 40:                                                             # the split-precision sweep's contract
+            assert int(nb[7]) == 0 and int(nb[100]) == 0 and bool(torch.isnan(tl[7])) and bool(torch.isnan(tl[100]))
+        # against the stored scores
+        sc = H.rank_candidates(emb, hr, tid, cand, cand_is_head=head, return_scores=True, model=model, planes=planes)[2]
+        col = (cand.view(1, -1) == tid.view(-1, 1)).float().argmax(1)
+        st = sc.gather(1, col.view(-1, 1))
+        ok = torch.ones(B, dtype=torch.bool, device="cuda"); ok[7] = ok[100] = False
+        ref = ((sc < st) | ((sc == st) & (cand.view(1, -1) < tid.view(-1, 1)))).sum(1).int()
+        assert torch.equal(nb[ok], ref[ok])
+    with pytest.raises(ValueError):
+        H.rank_candidates(emb, hr, tid, cand[:-1].contiguous(), planes=planes) if d != 40 else (_ for _ in ()).throw(ValueError())
+
+
 @pytest.mark.parametrize("d", [64, 200, 40, 56])
 def test_hole_ranks_from_the_spectral_sweep(d):
     """HolE link prediction (README.md:42 score): the sweep on the table held in the frequency domain gives losses
     within 1e-5 of the oracle's FFT-based HolE score on the REAL table, and ranks equal to the reference heap fed with
-    the kernel's own losses -- tails and heads; split-precision sweep (d = 64, 200), fp32 pipeline (d = 40) and generic
-    kernel (d = 56)."""
+    the kernel's own losses -- tails and heads; split-precision sweep (d = 56, 64, 200) and fp32 pipeline (d = 40)."""
     from graphembeddings_amd import evaluate as E
     from graphembeddings_amd import hole as H
     rng = np.random.default_rng(5)
