@@ -370,6 +370,29 @@ def test_score_candidates_full_fb15k_shape(H):
         assert np.abs(out[rows, cols].numpy() - ref).max() < SCORE_TOL
 
 
+@pytest.mark.parametrize("d,B,K", [(104, 2100, 4200), (200, 8200, 1030), (56, 2100, 4200)])
+def test_score_candidates_large_sweeps_run_on_the_candidate_planes(H, d, B, K):
+    """ge_complex_score_1vK above 512 tiles of 128 x 128 takes the split-precision sweep in its scores-only mode (planes
+    built inside the call): ragged B and K, a k block that ends inside the row (d = 104, 56), raw scores and losses,
+    tails and heads -- 3,000 sampled cells and the whole last row / last column against the fp64 oracle."""
+    N = 6000
+    g = torch.Generator(device="cpu").manual_seed(d)
+    table = (torch.randn(N, d, generator=g) * 0.15)
+    table[::5] *= 4.0                                                   # rows outside the unit ball
+    hr = torch.stack([torch.randint(50, N, (B,), generator=g), torch.randint(0, 50, (B,), generator=g)], 1).int()
+    cand = torch.randint(50, N, (K,), generator=g).int()
+    t64 = table.numpy().astype(np.float64)
+    rows = torch.cat([torch.randint(0, B, (3000,), generator=g), torch.full((K,), B - 1), torch.arange(B)])
+    cols = torch.cat([torch.randint(0, K, (3000,), generator=g), torch.arange(K), torch.full((B,), K - 1)])
+    for cand_is_head in (False, True):
+        fixed, c, rel = hr[rows, 0].numpy(), cand[cols].numpy(), hr[rows, 1].numpy()
+        tr = np.stack([c, fixed, rel], 1) if cand_is_head else np.stack([fixed, c, rel], 1)
+        out = H.score_candidates(table.cuda(), hr.cuda(), cand.cuda(), cand_is_head=cand_is_head).cpu()
+        assert np.abs(out[rows, cols].numpy() - O.evaluate_triples(tr, t64)[:, 0]).max() < SCORE_TOL
+        raw = H.score_candidates(table.cuda(), hr.cuda(), cand.cuda(), cand_is_head=cand_is_head, apply_sigmoid=False).cpu()
+        assert np.abs(raw[rows, cols].numpy() - np.asarray(O.complex_score(tr, t64)).reshape(-1)).max() < SCORE_TOL
+
+
 # ---------------------------------------------------------------- row-sharded path, HIP kernels
 @pytest.mark.parametrize("shape", ["fb15k", "config4"])
 def test_sharded_trainer_single_rank_uses_hip_kernels(H, shape):

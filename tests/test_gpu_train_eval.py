@@ -147,6 +147,27 @@ def test_rank_planes_built_once_equal_planes_built_per_call(d, model):
         H.rank_candidates(emb, hr, tid, cand[:-1].contiguous(), planes=planes) if d != 40 else (_ for _ in ()).throw(ValueError())
 
 
+@pytest.mark.parametrize("B,K", [(1, 1), (1, 33), (129, 31), (5, 128), (300, 129)])
+def test_rank_sweep_small_and_ragged_shapes(B, K):
+    """The split-precision sweep at its smallest and most ragged shapes (one row, one candidate; a candidate list shorter
+    than a wave's 32 columns; one row more than a row block; exactly one tile; one candidate more than a tile): counts
+    equal those implied by the stored scores, nothing is counted for the padding."""
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(100 * B + K)
+    N, d = 400, 200
+    emb = torch.as_tensor((rng.standard_normal((N, d)) * 0.25).astype(np.float32)).cuda()
+    cand = torch.as_tensor(rng.permutation(np.arange(20, N))[:K].astype(np.int32)).cuda()
+    hr = torch.as_tensor(np.stack([rng.integers(20, N, B), rng.integers(0, 20, B)], 1).astype(np.int32)).cuda()
+    tid = cand[torch.as_tensor(rng.integers(0, K, B)).cuda()].contiguous()
+    for head in (False, True):
+        nb, nk = H.rank_candidates(emb, hr, tid, cand, cand_is_head=head)[:2]
+        nb1, _, sc = H.rank_candidates(emb, hr, tid, cand, cand_is_head=head, return_scores=True)
+        col = (cand.view(1, -1) == tid.view(-1, 1)).float().argmax(1)
+        st = sc.gather(1, col.view(-1, 1))
+        ref = ((sc < st) | ((sc == st) & (cand.view(1, -1) < tid.view(-1, 1)))).sum(1).int()
+        assert torch.equal(nb, ref) and torch.equal(nb1, ref) and int(nk.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("d", [64, 200, 40, 56])
 def test_hole_ranks_from_the_spectral_sweep(d):
     """HolE link prediction (README.md:42 score): the sweep on the table held in the frequency domain gives losses
