@@ -48,6 +48,7 @@ SYMBOLS = {
     "ge_rank_max_dim": (C.c_int, []),
     "ge_complex_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "ge_rank_1vK": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
+    "ge_known_cells": (C.c_int, [C.c_int, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p]),
     "ge_rank_planes_bytes": (_i64, [_i64, _i32, _i64]),
     "ge_rank_planes": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
     "ge_rank_1vK_planes": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p]),

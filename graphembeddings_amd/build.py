@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libge_hip.so")
-SOURCES = ["ge_capi.hip", "ge_complex.hip", "ge_rows.hip", "ge_hole.hip", "ge_1vk.hip", "ge_train.hip", "ge_prep_big.hip", "ge_shard.hip", "ge_spectral.hip", "ge_rank.hip", "ge_rank_pipe.hip", "ge_rank_f16.hip"]
+SOURCES = ["ge_capi.hip", "ge_complex.hip", "ge_rows.hip", "ge_hole.hip", "ge_1vk.hip", "ge_train.hip", "ge_prep_big.hip", "ge_shard.hip", "ge_spectral.hip", "ge_rank.hip", "ge_rank_pipe.hip", "ge_rank_f16.hip", "ge_known.hip"]
 HEADERS = ["ge_common.h", "ge_prep.h", "ge_complex_dev.h", "ge_rank_dev.h", os.path.join("..", "..", "include", "ge_hip.h")]
 ARCH = "gfx950"
 

@@ -14,6 +14,7 @@ int copy_if_launch(const float*, float*, int64_t, const int32_t*, hipStream_t);
 int rank_max_dim();
 int complex_rank_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float, int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, const void*, hipStream_t);
 int64_t rank_planes_bytes(int64_t, int32_t, int64_t);
+int known_cells_launch(int, const int64_t*, const int64_t*, int64_t, const int64_t*, const int64_t*, int64_t, const int64_t*, int64_t, int64_t, int32_t*, int32_t*, uint16_t*, hipStream_t);
 int rank_planes_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, void*, hipStream_t);
 int hole_spectral_launch(float*, int64_t, int32_t, int, hipStream_t);
 int hole_score_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, float*, hipStream_t);
@@ -321,6 +322,17 @@ int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int
                 float* scores_out, void* stream) {
   return ge_rank_1vK_planes(table, N, d, hr, B, true_id, cand, K, max_norm, model, cand_is_head, known_off, known_rc,
                             n_before, n_known_before, true_loss, scores_out, nullptr, stream);
+}
+
+int ge_known_cells(int pass, const int64_t* known_key, const int64_t* known_ent, int64_t M, const int64_t* fixed,
+                   const int64_t* rel, int64_t B, const int64_t* pos_of, int64_t n_rows, int64_t n_cand, int32_t* tile_scratch,
+                   int32_t* known_off, uint16_t* known_rc, void* stream) {
+  if (pass < 0 || pass > 1 || M < 0 || B < 0 || n_rows <= 0 || n_cand <= 0 || !tile_scratch || !known_off) return GE_EINVAL;
+  if (M > 0 && (!known_key || !known_ent)) return GE_EINVAL;
+  if (B > 0 && (!fixed || !rel || !pos_of)) return GE_EINVAL;
+  if (pass == 1 && !known_rc) return GE_EINVAL;
+  return known_cells_launch(pass, known_key, known_ent, M, fixed, rel, B, pos_of, n_rows, n_cand, tile_scratch, known_off,
+                            known_rc, (hipStream_t)stream);
 }
 
 int ge_complex_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,

@@ -41,34 +41,35 @@ class KnownIndex:
             return
         k = torch.as_tensor(np.asarray(known_triples, dtype=np.int64)).to(device)
         fixed, other = (k[:, 0], k[:, 1]) if side == "tail" else (k[:, 1], k[:, 0])
-        pairs = torch.unique(torch.stack([fixed * self.n_rows + k[:, 2], other], 1), dim=0)   # a set, like the
-        self.key, self.ent = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()                 # reference's dict of sets; sorted
+        # a set, like the reference's dict of sets (holE.py:413-422), sorted by (fixed, relation, other)
+        if self.n_rows ** 3 < 2 ** 63:      # one radix sort of the triple packed into an int64
+            packed = torch.unique_consecutive(torch.sort((fixed * self.n_rows + k[:, 2]) * self.n_rows + other)[0])
+            self.key, self.ent = (packed // self.n_rows).contiguous(), (packed % self.n_rows).contiguous()
+        else:
+            pairs = torch.unique(torch.stack([fixed * self.n_rows + k[:, 2], other], 1), dim=0)
+            self.key, self.ent = pairs[:, 0].contiguous(), pairs[:, 1].contiguous()
 
     def cells(self, fixed: torch.Tensor, rel: torch.Tensor, pos_of: torch.Tensor, n_cand: int):
         """(row, candidate position) of every known-true candidate of the query rows, as the per-tile lists
-        ge_complex_rank_1vK takes: (known_off int32 [tiles+1], known_rc int16)."""
+        ge_complex_rank_1vK takes: (known_off int32 [tiles+1], known_rc int16) -- ge_known_cells: a counting pass, the total
+        read back (the call's one synchronisation), a filling pass."""
         B = fixed.numel()
         dev = fixed.device
-        n_ct = (n_cand + 127) // 128
-        n_tiles = ((B + 127) // 128) * n_ct
-        q = fixed.to(torch.int64) * self.n_rows + rel.to(torch.int64)
-        lo = torch.searchsorted(self.key, q)
-        cnt = torch.searchsorted(self.key, q, right=True) - lo
-        total = int(cnt.sum())
-        if total == 0:
-            return torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int16, device=dev)
-        start = torch.cumsum(cnt, 0) - cnt
-        row = torch.repeat_interleave(torch.arange(B, device=dev), cnt)
-        ent = self.ent[lo[row] + (torch.arange(total, device=dev) - start[row])]
-        col = pos_of[ent]
-        ok = col >= 0
-        row, col = row[ok], col[ok]
-        tile = (row // 128) * n_ct + col // 128
-        tile, order = torch.sort(tile)
-        rc = ((row[order] % 128) * 128 + col[order] % 128).to(torch.int16)
-        off = torch.searchsorted(tile, torch.arange(n_tiles + 1, device=dev)).to(torch.int32)
-        if rc.numel() == 0:
-            rc = torch.zeros(1, dtype=torch.int16, device=dev)
+        if dev.type != "cuda" or pos_of.dtype != torch.int64 or not pos_of.is_cuda:
+            raise ValueError("KnownIndex.cells runs on the GPU (ge_known_cells): CUDA tensors, pos_of int64")
+        n_tiles = ((B + 127) // 128) * ((n_cand + 127) // 128)
+        off = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(max(n_tiles, 1), dtype=torch.int32, device=dev)
+        fixed, rel = fixed.to(torch.int64).contiguous(), rel.to(torch.int64).contiguous()
+        args = (self.key.data_ptr(), self.ent.data_ptr(), self.key.numel(), fixed.data_ptr(), rel.data_ptr(), B,
+                pos_of.data_ptr(), self.n_rows, n_cand, scratch.data_ptr(), off.data_ptr())
+        H._lib.call("ge_known_cells", 0, *args, None, H._stream())
+        total = int(off[-1])
+        rc = torch.empty(max(total, 1), dtype=torch.int16, device=dev)
+        if total:
+            H._lib.call("ge_known_cells", 1, *args, rc.data_ptr(), H._stream())
+        else:
+            rc.zero_()
         return off, rc
 
 

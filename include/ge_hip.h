@@ -243,6 +243,17 @@ int ge_rank_1vK_planes(const float* table, int64_t N, int32_t d, const int32_t* 
                        const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                        float* scores_out, const void* planes, void* stream);
 
+/* --- the known_off / known_rc lists of ge_rank_1vK from a sorted index of the known-true triples (the filter of
+ * holE.py:454-463, built by the reference as a dict of sets, holE.py:413-422).  known_key [M] ascending = fixed entity *
+ * n_rows + relation of every distinct known (fixed, other, relation); known_ent [M] = the other entity; fixed / rel [B] =
+ * the test rows; pos_of [n_rows] = position of an entity in the candidate list (-1: not a candidate).  Two passes:
+ *   pass 0  known_off [tiles + 1] <- offsets of every (128 rows x 128 candidates) tile's cells; known_off[tiles] = total
+ *   pass 1  known_rc [total] <- the cells, (row % 128) << 7 | (column % 128), in no particular order inside a tile
+ * tile_scratch: int32 [tiles], the same buffer in both passes.  All ids are int64 (the evaluator's dtype). */
+int ge_known_cells(int pass, const int64_t* known_key, const int64_t* known_ent, int64_t M, const int64_t* fixed,
+                   const int64_t* rel, int64_t B, const int64_t* pos_of, int64_t n_rows, int64_t n_cand, int32_t* tile_scratch,
+                   int32_t* known_off, uint16_t* known_rc, void* stream);
+
 /* --- the inner training loop of holE.py:340-362 (minus validation), enqueued natively: for
  * s in [0, n_steps): batch = triples[(first_row + s*B) .. +B) (rows of a device-resident, already
  * shuffled [T,3] int32 array, wrapping to row 0 when the next batch would run past T -- the

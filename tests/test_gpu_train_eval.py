@@ -147,6 +147,46 @@ def test_rank_planes_built_once_equal_planes_built_per_call(d, model):
         H.rank_candidates(emb, hr, tid, cand[:-1].contiguous(), planes=planes) if d != 40 else (_ for _ in ()).throw(ValueError())
 
 
+def test_known_cells_kernel_matches_brute_force():
+    from graphembeddings_amd import evaluate as E_
+    """ge_known_cells (evaluate.KnownIndex.cells): the per-(128 x 128)-tile lists of known-true cells the fused ranking
+    kernel takes, against a brute-force enumeration; duplicates in the known triples count once; a test row whose fixed
+    entity has no known triple and an empty index give empty lists."""
+    rng = np.random.default_rng(7)
+    N, R, B, K = 900, 6, 300, 700
+    known = np.stack([rng.integers(R, N, 4000), rng.integers(R, N, 4000), rng.integers(0, R, 4000)], 1)
+    known = np.concatenate([known, known[:500]])                    # duplicates
+    cand = np.sort(rng.permutation(np.arange(R, N))[:K])
+    pos_of = torch.full((N,), -1, dtype=torch.int64)
+    pos_of[torch.as_tensor(cand)] = torch.arange(K)
+    pos_dev = pos_of.cuda()
+    test = known[rng.integers(0, len(known), B)]
+    for side in ("tail", "head"):
+        fc, oc = (0, 1) if side == "tail" else (1, 0)
+        idx = E_.KnownIndex(known, N, side, torch.device("cuda"))
+        off, rc = idx.cells(torch.as_tensor(test[:, fc]).cuda(), torch.as_tensor(test[:, 2]).cuda(), pos_dev, K)
+        off, rc = off.cpu(), rc.cpu()
+        n_ct = (K + 127) // 128
+        got = set()
+        off = off.numpy()
+        for tile in range(len(off) - 1):
+            for v in rc.numpy()[off[tile]:off[tile + 1]].astype(np.int64):
+                got.add(((tile // n_ct) * 128 + v // 128, (tile % n_ct) * 128 + v % 128))
+        exp = set()
+        kn = {(int(a[fc]), int(a[2]), int(a[oc])) for a in known}
+        by = {}
+        for f, r, o in kn:
+            by.setdefault((f, r), []).append(o)
+        for i, t in enumerate(test):
+            for o in by.get((int(t[fc]), int(t[2])), []):
+                if pos_of[o] >= 0:
+                    exp.add((i, int(pos_of[o])))
+        assert got == exp and int(off[-1]) == len(exp)
+    empty = E_.KnownIndex(None, N, "tail", torch.device("cuda"))
+    off, rc = empty.cells(torch.as_tensor(test[:, 0]).cuda(), torch.as_tensor(test[:, 2]).cuda(), pos_dev, K)
+    assert int(off.abs().sum()) == 0 and off.numel() == ((B + 127) // 128) * ((K + 127) // 128) + 1
+
+
 @pytest.mark.parametrize("B,K", [(1, 1), (1, 33), (129, 31), (5, 128), (300, 129)])
 def test_rank_sweep_small_and_ragged_shapes(B, K):
     """The split-precision sweep at its smallest and most ragged shapes (one row, one candidate; a candidate list shorter

@@ -74,35 +74,18 @@ def test_sharded_planner_index_helpers():
     assert out.tolist() == sorted(out.tolist())
 
 
-def test_known_index_cells_match_brute_force():
-    """evaluate.KnownIndex (device-agnostic tensor code): the per-(128 x 128)-tile lists of known-true cells the
-    fused ranking kernel takes, against a brute-force enumeration; duplicates in the known triples count once."""
+def test_known_index_is_the_sorted_set_of_known_triples():
+    """evaluate.KnownIndex: key = fixed * n_rows + relation ascending, entities ascending inside a key, duplicates of the
+    known triples once -- the reference's dict of sets (holE.py:413-422) as two sorted arrays, tails and heads.  (The
+    per-tile cell lists built from it are the kernel ge_known_cells: tests/test_gpu_train_eval.py.)"""
     import torch
     rng = np.random.default_rng(7)
-    N, R, B, K = 900, 6, 300, 700
+    N, R = 900, 6
     known = np.stack([rng.integers(R, N, 4000), rng.integers(R, N, 4000), rng.integers(0, R, 4000)], 1)
     known = np.concatenate([known, known[:500]])                    # duplicates
-    cand = np.sort(rng.permutation(np.arange(R, N))[:K])
-    pos_of = torch.full((N,), -1, dtype=torch.int64)
-    pos_of[torch.as_tensor(cand)] = torch.arange(K)
-    test = known[rng.integers(0, len(known), B)]
     for side in ("tail", "head"):
         fc, oc = (0, 1) if side == "tail" else (1, 0)
         idx = E.KnownIndex(known, N, side, torch.device("cpu"))
-        off, rc = idx.cells(torch.as_tensor(test[:, fc]), torch.as_tensor(test[:, 2]), pos_of, K)
-        n_ct = (K + 127) // 128
-        got = set()
-        off = off.numpy()
-        for tile in range(len(off) - 1):
-            for v in rc.numpy()[off[tile]:off[tile + 1]].astype(np.int64):
-                got.add(((tile // n_ct) * 128 + v // 128, (tile % n_ct) * 128 + v % 128))
-        exp = set()
-        kn = {(int(a[fc]), int(a[2]), int(a[oc])) for a in known}
-        by = {}
-        for f, r, o in kn:
-            by.setdefault((f, r), []).append(o)
-        for i, t in enumerate(test):
-            for o in by.get((int(t[fc]), int(t[2])), []):
-                if pos_of[o] >= 0:
-                    exp.add((i, int(pos_of[o])))
-        assert got == exp and int(off[-1]) == len(exp)
+        got = list(zip(idx.key.tolist(), idx.ent.tolist()))
+        exp = sorted({(int(a[fc]) * N + int(a[2]), int(a[oc])) for a in known})
+        assert got == exp
