@@ -243,28 +243,23 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       const bool bad = fid < 0 || fid >= N || rid < 0 || rid >= N;
       const float* frow = table + (int64_t)(bad ? 0 : fid) * d;
       const float* rrow = table + (int64_t)(bad ? 0 : rid) * d;
-      // The thread's pieces of both rows (float4 j = qt, qt + 4, ... of each half) are requested together and kept: loaded
-      // pass by pass inside the loops the staging took one memory latency per iteration, 14 of them, and the set-up of
-      // a row block cost as much as sixteen candidate tiles (measured).  Requests are clamped into the row.
-      constexpr int kNIt = (2 * KKB + 3) / 4;                    // k / 4 = embedding_dim / 8 <= 2 KKB float4 per half-row
+      // Two compact loops (not unrolled: straight-line code that runs once per row block is fetched cold -- about 300
+      // cycles per 64 bytes of instructions, measured on the unrolled form of this staging and on a second copy of the
+      // MFMA loop), each requesting the next iteration's four float4 before this iteration's arithmetic.
       const int nj = k >> 2;
-      float4 fre[kNIt], fim[kNIt], rre[kNIt], rim[kNIt];
-#pragma unroll
-      for (int i = 0; i < kNIt; ++i) {
-        const int jc = min(qt + 4 * i, nj - 1);
-        fre[i] = *reinterpret_cast<const float4*>(frow + 4 * jc); fim[i] = *reinterpret_cast<const float4*>(frow + k + 4 * jc);
-        rre[i] = *reinterpret_cast<const float4*>(rrow + 4 * jc); rim[i] = *reinterpret_cast<const float4*>(rrow + k + 4 * jc);
-      }
+      auto ld4 = [&](const float* row, int j) -> float4 { return *reinterpret_cast<const float4*>(row + 4 * min(j, nj - 1)); };
       float ssf = 0.f, ssr = 0.f;
       // spectral HolE (ge_complex_dev.h): Hermitian weight 2 on every bin but element 0, which packs the two REAL
       // bins X_0 | X_k; norms and score carry the Parseval factor 1/d
-#pragma unroll
-      for (int i = 0; i < kNIt; ++i) {                           // pass 1: the two clip norms
-        const int j = qt + 4 * i;
-        if (j < nj) {
+      {
+        float4 nfre = ld4(frow, qt), nfim = ld4(frow + k, qt), nrre = ld4(rrow, qt), nrim = ld4(rrow + k, qt);
+#pragma unroll 1
+        for (int j = qt; j < nj; j += 4) {                       // pass 1: the two clip norms
+          const float4 fre = nfre, fim = nfim, rre = nrre, rim = nrim;
+          nfre = ld4(frow, j + 4); nfim = ld4(frow + k, j + 4); nrre = ld4(rrow, j + 4); nrim = ld4(rrow + k, j + 4);
           const float w0 = (spec && j != 0) ? 2.f : 1.f, w1 = spec ? 2.f : 1.f;   // element 0 of the row / the others
-          ssf += w0 * (fre[i].x * fre[i].x + fim[i].x * fim[i].x) + w1 * (fre[i].y * fre[i].y + fre[i].z * fre[i].z + fre[i].w * fre[i].w + fim[i].y * fim[i].y + fim[i].z * fim[i].z + fim[i].w * fim[i].w);
-          ssr += w0 * (rre[i].x * rre[i].x + rim[i].x * rim[i].x) + w1 * (rre[i].y * rre[i].y + rre[i].z * rre[i].z + rre[i].w * rre[i].w + rim[i].y * rim[i].y + rim[i].z * rim[i].z + rim[i].w * rim[i].w);
+          ssf += w0 * (fre.x * fre.x + fim.x * fim.x) + w1 * (fre.y * fre.y + fre.z * fre.z + fre.w * fre.w + fim.y * fim.y + fim.z * fim.z + fim.w * fim.w);
+          ssr += w0 * (rre.x * rre.x + rim.x * rim.x) + w1 * (rre.y * rre.y + rre.z * rre.z + rre.w * rre.w + rim.y * rim.y + rim.z * rim.z + rim.w * rim.w);
         }
       }
       ssf += __shfl_xor(ssf, 1, kWave); ssf += __shfl_xor(ssf, 2, kWave);
@@ -278,39 +273,42 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
       const float sa = clip_scale(ssf * inv_d, max_norm, i0) * clip_scale(ssr * inv_d, max_norm, i1) * inv_d * kQScale;
       _Float16* ah = lds.Ah + qrow * kSA;
       _Float16* am = lds.Am + qrow * kSA;
+      {
+        float4 nfre = ld4(frow, qt), nfim = ld4(frow + k, qt), nrre = ld4(rrow, qt), nrim = ld4(rrow + k, qt);
+#pragma unroll 1
+        for (int j = qt; j < nj; j += 4) {                       // pass 2: q * sa * 2^8 -> high halves and remainders
+          const float4 fre = nfre, fim = nfim, rre = nrre, rim = nrim;
+          nfre = ld4(frow, j + 4); nfim = ld4(frow + k, j + 4); nrre = ld4(rrow, j + 4); nrim = ld4(rrow + k, j + 4);
+          const float fr[4] = {fre.x, fre.y, fre.z, fre.w}, fi[4] = {fim.x, fim.y, fim.z, fim.w};
+          const float rr[4] = {rre.x, rre.y, rre.z, rre.w}, ri[4] = {rim.x, rim.y, rim.z, rim.w};
+          float qre[4], qim[4];
 #pragma unroll
-      for (int it = 0; it < kNIt; ++it) {                        // pass 2: q * sa * 2^8 -> high halves and remainders
-        const int j = qt + 4 * it;
-        if (j >= nj) continue;
-        const float fr[4] = {fre[it].x, fre[it].y, fre[it].z, fre[it].w}, fi[4] = {fim[it].x, fim[it].y, fim[it].z, fim[it].w};
-        const float rr[4] = {rre[it].x, rre[it].y, rre[it].z, rre[it].w}, ri[4] = {rim[it].x, rim[it].y, rim[it].z, rim[it].w};
-        float qre[4], qim[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool packed = spec && j == 0 && i == 0;
-          if (packed) {          // two independent real dimensions: products of the re slots and of the im slots
-            qre[i] = fr[i] * rr[i];
-            qim[i] = fi[i] * ri[i];
-          } else if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
-            qre[i] = fr[i] * rr[i] - fi[i] * ri[i];
-            qim[i] = fr[i] * ri[i] + fi[i] * rr[i];
-          } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
-            qre[i] = rr[i] * fr[i] + ri[i] * fi[i];
-            qim[i] = -(ri[i] * fr[i] - rr[i] * fi[i]);
+          for (int i = 0; i < 4; ++i) {
+            const bool packed = spec && j == 0 && i == 0;
+            if (packed) {          // two independent real dimensions: products of the re slots and of the im slots
+              qre[i] = fr[i] * rr[i];
+              qim[i] = fi[i] * ri[i];
+            } else if (!cand_is_head) {   // q = h * r ; score = Re(q conj t)
+              qre[i] = fr[i] * rr[i] - fi[i] * ri[i];
+              qim[i] = fr[i] * ri[i] + fi[i] * rr[i];
+            } else {               // Re(h r conj t) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
+              qre[i] = rr[i] * fr[i] + ri[i] * fi[i];
+              qim[i] = -(ri[i] * fr[i] - rr[i] * fi[i]);
+            }
+            if (spec && !packed) { qre[i] *= 2.f; qim[i] *= 2.f; }   // Hermitian weight
           }
-          if (spec && !packed) { qre[i] *= 2.f; qim[i] *= 2.f; }   // Hermitian weight
-        }
-        h4 rh, rm, ih, im;
+          h4 rh, rm, ih, im;
 #pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-          h2 a, b;
-          h_split(qre[i] * sa, qre[i + 1] * sa, a, b);
-          rh[i] = a.x; rh[i + 1] = a.y; rm[i] = b.x; rm[i + 1] = b.y;
-          h_split(qim[i] * sa, qim[i + 1] * sa, a, b);
-          ih[i] = a.x; ih[i + 1] = a.y; im[i] = b.x; im[i + 1] = b.y;
+          for (int i = 0; i < 4; i += 2) {
+            h2 a, b;
+            h_split(qre[i] * sa, qre[i + 1] * sa, a, b);
+            rh[i] = a.x; rh[i + 1] = a.y; rm[i] = b.x; rm[i + 1] = b.y;
+            h_split(qim[i] * sa, qim[i + 1] * sa, a, b);
+            ih[i] = a.x; ih[i + 1] = a.y; im[i] = b.x; im[i + 1] = b.y;
+          }
+          *reinterpret_cast<h4*>(ah + 4 * j) = rh; *reinterpret_cast<h4*>(am + 4 * j) = rm;          // (row stride, k: multiples of 4)
+          *reinterpret_cast<h4*>(ah + k + 4 * j) = ih; *reinterpret_cast<h4*>(am + k + 4 * j) = im;
         }
-        *reinterpret_cast<h4*>(ah + 4 * j) = rh; *reinterpret_cast<h4*>(am + 4 * j) = rm;          // (row stride, k: multiples of 4)
-        *reinterpret_cast<h4*>(ah + k + 4 * j) = ih; *reinterpret_cast<h4*>(am + k + 4 * j) = im;
       }
       if (qt == 0) {
         for (int c = d; c < 16 * KKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; }       // k padding
@@ -351,58 +349,65 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     };
     int item = take(), item_next = take();
     const int s0 = 4 * (ct0 + (item >> 1)) + wn;
-    // ---- the true candidates: a tile whose candidate rows are the block's 128 true entities (this wave: 32 of them)
+    // ---- the first pass of the loop below (ranks): the true candidates -- a tile whose candidate rows are the block's 128
+    // true entities (this wave: 32 of them, gathered by position), through the SAME copy of the MFMA loop as the sweep's
+    // blocks (a second copy, fetched cold once per row block, took six tiles' time)
+    bool diag = MODE != 2;
+    const _Float16* cur = slice_src(s0);
     if constexpr (MODE != 2) {
       const int pos = lds.tP[wn * 32 + li];
       const int pc = pos < 0 ? 0 : pos;
-      const _Float16* dsrc = planes + (int64_t)(pc >> 5) * kSliceHalves + (pc & 31) * 16 + lh * 8;
-#pragma unroll
-      for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], dsrc, j);
-      h_mfma_loop<KKB>(lds, dsrc, slice_src(s0), Bq, acc, wm, li, lh);   // leaves the first block's leading operands in Bq
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-          if (rl == wn * 32 + li) lds.eT[rl] = acc[tm][q];        // raw score, row scale still to come
-        }
-      __syncthreads();
-      if (t < kRB) {
-        // Bracket of the true candidate's raw score.  With g = e (1 - e) the sigmoid's slope at the true score and
-        // w = 1e-6 / g <= 0.1, the slope anywhere inside [xs - w, xs + w] is >= g exp(-w) (the sigmoid is concave on one
-        // side: a first-order bound alone is not enough), so a candidate whose scaled score lies outside has a loss that
-        // differs by >= 0.9e-6, three times what the roundings of x * sA and of the 4-instruction sigmoid
-        // (< 1.5e-7 each side) can move: outside the bracket the order of the losses is the order of the raw scores.
-        // Near saturation (g < 1e-5, |score| > 11.5) no finite bracket gives that margin: it is infinite there and
-        // every candidate of the row takes the exact comparison.  A true entity that is not among the candidates has
-        // no rank: NaN bracket, NaN loss, no bit is ever set.
-        const float xp = lds.tP[t] < 0 ? __builtin_nanf("") : lds.eT[t], sa = lds.sA[t];
-        const float xs = xp * sa, e = rank_sigmoid(xs), gs = e * (1.0f - e);
-        const float wx = gs < 1e-5f ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
-        const float wq = wx / sa;
-        lds.lohi[t] = make_float2(xp - wq, xp + wq);
-        lds.eT[t] = e;
-        if (true_loss && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
-      }
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], slice_src(s0), j);
+      cur = planes + (int64_t)(pc >> 5) * kSliceHalves + (pc & 31) * 16 + lh * 8;
     }
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], cur, j);
     int raw_reg[2][2] = {{0, 0}, {0, 0}};                         // lane r < 32: bits counted for row half*64 + tm*32 + r
 
     // ---- the sweep: no barrier until the row block is done
-    int32_t kn0, kn1, kn0_next, kn1_next;
+    int32_t kn0 = 0, kn1 = 0, kn0_next, kn1_next;
     known_of(ct0 + (item >> 1), kn0_next, kn1_next);
-    while (item < n_items) {
-      const int ct = ct0 + (item >> 1), wmi = item & 1;
-      const int s = 4 * ct + wn, s_next = 4 * (ct0 + (item_next >> 1)) + wn;
-      const int64_t col = (int64_t)s * kSL + li;                 // this lane's candidate
-      // (the next block's known-cell range is requested BEFORE the MFMA loop: it is a scalar load, and the wait in front of
-      // the epilogue -- for the brackets -- waits for everything on that counter)
-      kn0 = kn0_next; kn1 = kn1_next;
-      known_of(ct0 + (item_next >> 1), kn0_next, kn1_next);
-      h_mfma_loop<KKB>(lds, slice_src(s), slice_src(s_next), Bq, acc, wmi, li, lh);
+    while (diag || item < n_items) {
+      const int ct = ct0 + (item >> 1), wmi = diag ? wm : (item & 1);
+      const int64_t col = (int64_t)(4 * ct + wn) * kSL + li;     // this lane's candidate
+      const _Float16* nxt = slice_src(4 * (ct0 + ((diag ? item : item_next) >> 1)) + wn);
+      if (!diag) {
+        // (the next block's known-cell range is requested BEFORE the MFMA loop: it is a scalar load, and the wait in front
+        // of the epilogue -- for the brackets -- waits for everything on that counter)
+        kn0 = kn0_next; kn1 = kn1_next;
+        known_of(ct0 + (item_next >> 1), kn0_next, kn1_next);
+      }
+      h_mfma_loop<KKB>(lds, cur, nxt, Bq, acc, wmi, li, lh);     // leaves the next block's leading operands in Bq
+      cur = nxt;
+      if (diag) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rl = wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            if (rl == wn * 32 + li) lds.eT[rl] = acc[tm][q];      // raw score, row scale still to come
+          }
+        __syncthreads();
+        if (t < kRB) {
+          // Bracket of the true candidate's raw score.  With g = e (1 - e) the sigmoid's slope at the true score and
+          // w = 1e-6 / g <= 0.1, the slope anywhere inside [xs - w, xs + w] is >= g exp(-w) (the sigmoid is concave on one
+          // side: a first-order bound alone is not enough), so a candidate whose scaled score lies outside has a loss that
+          // differs by >= 0.9e-6, three times what the roundings of x * sA and of the 4-instruction sigmoid
+          // (< 1.5e-7 each side) can move: outside the bracket the order of the losses is the order of the raw scores.
+          // Near saturation (g < 1e-5, |score| > 11.5) no finite bracket gives that margin: it is infinite there and
+          // every candidate of the row takes the exact comparison.  A true entity that is not among the candidates has
+          // no rank: NaN bracket, NaN loss, no bit is ever set.
+          const float xp = lds.tP[t] < 0 ? __builtin_nanf("") : lds.eT[t], sa = lds.sA[t];
+          const float xs = xp * sa, e = rank_sigmoid(xs), gs = e * (1.0f - e);
+          const float wx = gs < 1e-5f ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
+          const float wq = wx / sa;
+          lds.lohi[t] = make_float2(xp - wq, xp + wq);
+          lds.eT[t] = e;
+          if (true_loss && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
+        }
+        __syncthreads();
+        diag = false;
+        continue;
+      }
       item = item_next;
       item_next = take();
       // the brackets of this lane's 32 rows, requested together (read score by score -- a wait on the LDS queue in front
