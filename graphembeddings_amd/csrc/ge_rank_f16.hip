@@ -1,8 +1,8 @@
 // ge_rank_f16.hip -- the split-precision link-prediction sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip):
 // f16 MFMAs on pre-split candidate planes, eight free-running waves per workgroup (two per SIMD).
 //
-// Why this shape (tools/probes/mfma_gap_probe.hip -> profiles/r03_mfma_gap_probe.txt, tools/probes/rank_phase_probe.py
-// and the ablations recorded in DESIGN.md section 9):
+// Why this shape (tools/probes/mfma_gap_probe.hip -> profiles/r03_mfma_gap_probe.txt; s_memtime stamps per phase and
+// ablated builds, recorded in DESIGN.md section 9):
 //   * with one wave per SIMD the shadow of a v_mfma_f32_32x32x16_f16 hides four or five INDEPENDENT VALU instructions
 //     and next to nothing of the rank epilogue's compare -> scalar -> v_addc / v_writelane chains: cutting the epilogue
 //     into the gaps of the next tile's MFMAs gained nothing (measured).  A second wave on the SIMD hides it -- if it
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], cur, j);
     int raw_reg[2][2] = {{0, 0}, {0, 0}};                         // lane r < 32: bits counted for row half*64 + tm*32 + r
 
-    // ---- the sweep: no barrier until the row block is done
+    // ---- the sweep: behind the true-candidate pass no barrier until the row block is done
     int32_t kn0 = 0, kn1 = 0, kn0_next, kn1_next;
     known_of(ct0 + (item >> 1), kn0_next, kn1_next);
     while (diag || item < n_items) {
