@@ -208,6 +208,37 @@ def test_rank_sweep_small_and_ragged_shapes(B, K):
         assert torch.equal(nb, ref) and torch.equal(nb1, ref) and int(nk.abs().sum()) == 0
 
 
+def test_rank_sweep_many_candidates():
+    """150,001 candidates (1,172 tiles of 128, the last with one column; 125 MB of planes), 130 test rows, ids up to
+    200,000: the counts of the rank-only sweep equal those implied by the stored scores, and with a known-true list the
+    filtered counts equal a direct evaluation on those scores."""
+    from graphembeddings_amd import evaluate as E_
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(77)
+    N, d, B, K = 200_000, 200, 130, 150_001
+    emb = (torch.randn(N, d, generator=torch.Generator().manual_seed(5)) * 0.2).cuda()
+    cand_np = rng.permutation(np.arange(100, N))[:K].astype(np.int32)
+    cand = torch.as_tensor(cand_np).cuda()
+    hr = torch.as_tensor(np.stack([rng.integers(100, N, B), rng.integers(0, 100, B)], 1).astype(np.int32)).cuda()
+    tid = cand[torch.as_tensor(rng.integers(0, K, B)).cuda()].contiguous()
+    known = np.stack([np.repeat(hr[:, 0].cpu().numpy(), 40), rng.choice(cand_np, 40 * B), np.repeat(hr[:, 1].cpu().numpy(), 40)], 1)
+    pos_of = torch.full((N,), -1, dtype=torch.int64, device="cuda")
+    pos_of[cand.long()] = torch.arange(K, device="cuda")
+    off, rc = E_.KnownIndex(known, N, "tail", torch.device("cuda")).cells(hr[:, 0].long(), hr[:, 1].long(), pos_of, K)
+    planes = H.RankPlanes(emb, cand)
+    nb, nk = H.rank_candidates(emb, hr, tid, cand, known_off=off, known_rc=rc, planes=planes)[:2]
+    sc = H.rank_candidates(emb, hr, tid, cand, return_scores=True, planes=planes)[2]
+    col = pos_of[tid.long()]
+    st = sc.gather(1, col.view(-1, 1))
+    before = (sc < st) | ((sc == st) & (cand.view(1, -1) < tid.view(-1, 1)))
+    assert torch.equal(nb, before.sum(1).int())
+    kn = torch.zeros(B, dtype=torch.int64, device="cuda")
+    cells = {(int(r), int(pos_of[int(e)])) for r, e in zip(np.repeat(np.arange(B), 40), known[:, 1])}
+    rows = torch.as_tensor([c[0] for c in cells]).cuda(); cols = torch.as_tensor([c[1] for c in cells]).cuda()
+    kn.index_add_(0, rows, before[rows, cols].long())
+    assert torch.equal(nk.long(), kn)
+
+
 @pytest.mark.parametrize("d", [64, 200, 40, 56])
 def test_hole_ranks_from_the_spectral_sweep(d):
     """HolE link prediction (README.md:42 score): the sweep on the table held in the frequency domain gives losses
