@@ -1,6 +1,6 @@
 // ge_rank_pipe.hip -- the link-prediction ranking sweep (holE.py:427-472, 564-575; semantics in ge_rank.hip) on the fp32
 // MFMA, software-pipelined for one wave per SIMD.  It serves what the split-precision sweep (ge_rank_f16.hip, tried
-// first by sweep_pipe_launch) does not: embedding_dim % 8 == 0 below 56 or above 208, and max_norm > 8.
+// first by sweep_pipe_launch) does not: embedding_dim % 8 == 0 below 56, and max_norm > 8.
 //
 // What the microbenchmark (tools/probes/mfma_probe.hip) says about v_mfma_f32_32x32x2_f32 on gfx950 with one
 // wave per SIMD (the Q operand fills the LDS, so a CU holds one workgroup):
@@ -563,7 +563,7 @@ int sweep_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* h
                       const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                       const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                       float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
-  {   // embedding_dim % 8 == 0 in 56 ... 208, max_norm <= 8: the split-precision sweep (ge_rank_f16.hip)
+  {   // embedding_dim % 8 == 0 in 56 ... 232, max_norm <= 8: the split-precision sweep (ge_rank_f16.hip)
     const int rc = sweep_f16_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
                                     skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, planes_ws, st);
     if (rc != GE_ENOTSUP) return rc;
