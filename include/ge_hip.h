@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE_VERSION 300 /* 0.3.0: ge_shard_* (row-sharded step planned natively), multi-workgroup step sort */
+#define GE_VERSION 310 /* 0.3.1: + ge_rank_planes / ge_rank_1vK_planes (candidate planes built once), ge_known_cells */
 
 /* argument errors (negative, -errno style) */
 #define GE_EINVAL (-22)  /* bad dimension / null pointer / misaligned buffer */
