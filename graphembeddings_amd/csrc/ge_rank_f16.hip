@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         lds.tI[qrow] = tid;
         lds.tP[qrow] = (tid >= 0 && tid < N) ? pos_of[tid] : -1;
       }
-      if (t < 4) lds.next[t] = 0;
+      if (t < 4) lds.next[t] = 2;                                // (blocks 0 and 1 of a slice go to its two waves up front)
     }
     __syncthreads();
 
@@ -340,14 +340,15 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     // out from a counter to the two waves that own the slice (w = wn and wn + 4: the two waves of one SIMD).  With a fixed
     // row half each, the older wave of the SIMD won every issue arbitration, finished 14 tiles early and waited 11 % of
     // the kernel at the closing barrier while its partner ran alone, MFMA loop and epilogue back to back (measured;
-    // alternating s_setprio did not change it).  A wave holds two blocks: the one it computes and the one it prefetches.
+    // alternating s_setprio did not change it).  A wave holds two blocks: the one it computes and the one it prefetches
+    // (the first is block wm, so a row block with a single tile still keeps both waves busy).
     const int n_items = 2 * (ct1 - ct0);
     auto take = [&]() -> int {
       int v = 0;
       if (lane == 0) v = atomicAdd(&lds.next[wn], 1);
       return __builtin_amdgcn_readfirstlane(v);
     };
-    int item = take(), item_next = take();
+    int item = wm, item_next = take();
     const int s0 = 4 * (ct0 + (item >> 1)) + wn;
     // ---- the first pass of the loop below (ranks): the true candidates -- a tile whose candidate rows are the block's 128
     // true entities (this wave: 32 of them, gathered by position), through the SAME copy of the MFMA loop as the sweep's
