@@ -350,7 +350,8 @@ static size_t rank_lds_bytes(int d) {
   return sizeof(float) * ((size_t)kRB * lda + 2 * kRB * kLdb + 3 * kRB) + sizeof(unsigned) * kRB * 4 + sizeof(int) * 2 * kRB;
 }
 
-int rank_max_dim() { return 232; }   // Q (128 x (d+1) floats) + two candidate chunks must fit the CU's 160 KiB
+int rank_max_dim() { return 288; }   // the split-precision sweep's Q planes fill the LDS at 18 k blocks (max_norm <= 8);
+constexpr int kRankMaxDimF32 = 232;  // the fp32 kernels: Q (128 x (d+1) floats) + two candidate chunks must fit the CU's 160 KiB
 
 int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                             const int32_t* true_id, const int32_t* cand, int64_t K, float max_norm, int cand_is_head,
@@ -365,6 +366,7 @@ int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int3
                                     raw_cnt, skip_cnt, true_loss, scores_out, spec, planes_ws, st);
     if (rc != GE_ENOTSUP) return rc;
   }
+  if (d > kRankMaxDimF32) return GE_ENOTSUP;                    // (233 ... 288 with max_norm > 8)
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
   if (n_rb > 65535) return GE_ENOTSUP;
   // column splits: enough workgroups for ~4 waves of the 256 CUs, never more than column tiles

@@ -23,7 +23,7 @@ int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                      float* scores_out, int spec, const void* planes_ws, hipStream_t st);
 
-// ge_rank_f16.hip: the split-precision sweep (embedding_dim % 8 == 0 in 56 ... 232, max_norm <= 8), ranks or scores.
+// ge_rank_f16.hip: the split-precision sweep (embedding_dim % 8 == 0 in 56 ... 288, max_norm <= 8), ranks or scores.
 // planes_ws: the candidates' fp16 planes + entity -> position map (rank_planes_launch into rank_planes_bytes bytes, 256-byte
 // aligned) for the same (table, cand, max_norm, spec); NULL: built inside, in a stream-ordered allocation.
 int64_t rank_planes_bytes(int64_t N, int32_t d, int64_t K);

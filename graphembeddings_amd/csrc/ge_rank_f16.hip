@@ -23,7 +23,7 @@
 // x * 2^8 = hi + mid with two fp16 values (round toward zero, so mid has hi's sign) is exact to 22 bits, and
 //     q . t  =  2^-16 (qh.th + qh.tm + qm.th)  +  O(2^-22) per product
 // accumulated in fp32: three f16 MFMAs per 16-wide k block.  Q (pre-multiplied by the rows' clip scales) sits in LDS
-// as two fp16 planes for the whole row block.  The kernel is compiled per number of k blocks (embedding_dim 56 ... 232,
+// as two fp16 planes for the whole row block.  The kernel is compiled per number of k blocks (embedding_dim 56 ... 288,
 // any multiple of 8); embedding_dim itself is a run-time value.
 // Epilogue: raw scores against a bracket of the true candidate's raw score, bits into a row-major bitmap by
 // v_writelane, the exact fp32 comparison (id tie-break) only for scores inside the bracket -- the outcome equals
@@ -61,7 +61,7 @@ struct HCfg {
   static constexpr int kKB = KKB;                   // k blocks of 16 (the last zero padded behind embedding_dim)
   static constexpr int kChunks = (KKB + 1) / 2;     // 32-column pieces of a row (the pre-pass's unit)
   static constexpr int kSA = 16 * KKB + 8;          // halves per Q row (+16 bytes: ds_read_b128 of 32 rows hits 32 bank groups)
-  static_assert(KKB >= 4 && KKB <= 15, "embedding_dim 56 ... 232 (LDS: the Q planes, 127 KB at 15 k blocks)");
+  static_assert(KKB >= 4 && KKB <= 18, "embedding_dim 56 ... 288 (LDS: the Q planes, 152 KB at 18 k blocks)");
 };
 constexpr float kQScale = 256.f;        // both operands: |q|, |t * clip| <= max_norm^2 resp. max_norm sqrt(d/2)
 constexpr int kOpHalves = kSL * 16;     // one operand fetch of one wave in `planes`: [32 candidates][16 columns], 1 KiB
@@ -597,7 +597,7 @@ int f16_cu_count() {
   return cus;
 }
 
-inline bool f16_dim_ok(int32_t d, float max_norm) { return d % 8 == 0 && d >= 56 && d <= 232 && max_norm <= 8.f; }
+inline bool f16_dim_ok(int32_t d, float max_norm) { return d % 8 == 0 && d >= 56 && d <= 288 && max_norm <= 8.f; }
 inline int64_t pos_bytes(int64_t N) { return (N * (int64_t)sizeof(int32_t) + 255) / 256 * 256; }
 inline int64_t planes_slices(int64_t K) { return 4 * ((K + kRB - 1) / kRB); }   // whole 128-candidate tiles
 
@@ -632,13 +632,13 @@ int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, 
   switch (((d) + 15) / 16) {                                                                          \
     case 4: CALL(4); case 5: CALL(5); case 6: CALL(6); case 7: CALL(7); case 8: CALL(8);              \
     case 9: CALL(9); case 10: CALL(10); case 11: CALL(11); case 12: CALL(12); case 13: CALL(13);      \
-    case 14: CALL(14); case 15: CALL(15);                                                             \
+    case 14: CALL(14); case 15: CALL(15); case 16: CALL(16); case 17: CALL(17); case 18: CALL(18);    \
     default: return GE_ENOTSUP;                                                                       \
   }
 
 // bytes of the candidate planes of a K-candidate sweep over an N-row table (0: embedding_dim has no split-precision sweep)
 int64_t rank_planes_bytes(int64_t N, int32_t d, int64_t K) {
-  if (d % 8 != 0 || d < 56 || d > 232 || N <= 0 || K <= 0) return 0;
+  if (d % 8 != 0 || d < 56 || d > 288 || N <= 0 || K <= 0) return 0;
   const int64_t kkb = (d + 15) / 16;
   return pos_bytes(N) + planes_slices(K) * kkb * 2 * kOpHalves * (int64_t)sizeof(_Float16);
 }
@@ -664,7 +664,7 @@ int rank_planes_launch(const float* table, int64_t N, int32_t d, const int32_t* 
 #undef GE_CALL
 }
 
-// The split-precision sweep: embedding_dim % 8 == 0 in 56 ... 232 (k blocks 4 ... 15), max_norm <= 8
+// The split-precision sweep: embedding_dim % 8 == 0 in 56 ... 288 (k blocks 4 ... 18), max_norm <= 8
 // (|q sa (1/d)| <= 2 max_norm^2, |t clip| <= max_norm sqrt(d/2): x 2^8 inside fp16).  GE_ENOTSUP otherwise.
 // planes_ws: the candidates' planes from rank_planes_launch for the same (table, cand, max_norm, spec), or NULL -- then
 // they are built here in a stream-ordered allocation (one more pass over the K candidate rows).
@@ -673,7 +673,7 @@ int sweep_f16_launch(const float* table, int64_t N, int32_t d, const int32_t* hr
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                      float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
   if (!f16_dim_ok(d, max_norm)) return GE_ENOTSUP;
-  static_assert(h_lds_bytes<15>() <= 160 * 1024, "LDS of the largest instantiation");
+  static_assert(h_lds_bytes<18>() <= 160 * 1024, "LDS of the largest instantiation");
   void* own = nullptr;
   if (!planes_ws) {
     hipError_t e = hipMallocAsync(&own, (size_t)rank_planes_bytes(N, d, K), st);

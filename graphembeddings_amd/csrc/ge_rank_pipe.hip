@@ -563,7 +563,7 @@ int sweep_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* h
                       const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                       const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                       float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
-  {   // embedding_dim % 8 == 0 in 56 ... 232, max_norm <= 8: the split-precision sweep (ge_rank_f16.hip)
+  {   // embedding_dim % 8 == 0 in 56 ... 288, max_norm <= 8: the split-precision sweep (ge_rank_f16.hip)
     const int rc = sweep_f16_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
                                     skip_cnt, true_loss, scores_out, spec, scores_only, sweep_flags, planes_ws, st);
     if (rc != GE_ENOTSUP) return rc;

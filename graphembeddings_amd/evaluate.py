@@ -93,7 +93,7 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
         raise ValueError(f"unknown model {model!r}")
     dev = embeddings.device
     d = embeddings.shape[1]
-    can_fuse = d % 8 == 0 and d <= H.rank_max_dim()
+    can_fuse = d % 8 == 0 and d <= H.rank_max_dim() and (d <= 232 or max_norm <= 8.0)   # (fp32 kernels: up to 232)
     if fused is None:
         fused = can_fuse
     if model != "complex":

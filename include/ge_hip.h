@@ -204,10 +204,10 @@ int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t
  * [ceil(B/128) * ceil(K/128) + 1] int32 offsets into known_rc, whose entries are (row % 128) << 7 | (column % 128)
  * (both NULL: no filtering).  No [B,K] score matrix is written: the counting is the epilogue of the fp32-MFMA
  * GEMM (E = sigmoid(score) as in ge_complex_score_1vK).  true_loss (nullable) [B] receives E_i,true;
- * scores_out (nullable) [B,K] receives every loss -- for tests.  d must be a multiple of 8 and <= ge_rank_max_dim()
+ * scores_out (nullable) [B,K] receives every loss -- for tests.  d must be a multiple of 8 and <= ge_rank_max_dim() (288; above 232 only with max_norm <= 8)
  * (the block's Q operand lives in LDS for the whole sweep), table 16-byte aligned; otherwise GE_ENOTSUP and the
  * caller falls back to ge_complex_score_1vK.
- * Arithmetic: fp32 MFMA with fp32 accumulation; for every d % 8 == 0 in 56 ... 232 and max_norm <= 8 the operands are split
+ * Arithmetic: fp32 MFMA with fp32 accumulation; for every d % 8 == 0 in 56 ... 288 and max_norm <= 8 the operands are split
  * into fp16 high halves and remainders (22 bits each, after the clip scales, so no fp16 overflow for any table) and
  * multiplied by three f16 MFMAs with fp32 accumulation -- losses within 1e-7 of the fp64 restatement either way
  * (ge_complex_score_1vK takes the same route for large sweeps at those dims). */
@@ -225,7 +225,7 @@ int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int
                 const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                 float* scores_out, void* stream);
 
-/* The split-precision sweep (embedding_dim % 8 == 0 in 56 ... 232, max_norm <= 8) reads the candidates as pre-split fp16
+/* The split-precision sweep (embedding_dim % 8 == 0 in 56 ... 288, max_norm <= 8) reads the candidates as pre-split fp16
  * planes (high halves and remainders of row * clip scale * 2^8, laid out per 64-candidate tile) plus an entity ->
  * candidate-position map.  ge_rank_1vK builds them on every call (one pass over the K candidate rows, in a
  * stream-ordered allocation); a caller that ranks many batches against the same (table, cand, max_norm, model) --

@@ -53,12 +53,12 @@ def _all_scores(emb, test, cand, side, fused):
 
 
 @pytest.mark.parametrize("fused,d", [(True, 64), (False, 64), (True, 96), (True, 128), (True, 160), (True, 192), (True, 200), (True, 56),
-                                     (True, 72), (True, 104), (True, 120), (True, 136), (True, 176), (True, 208), (True, 216), (True, 232), (True, 48), (True, 40)])
+                                     (True, 72), (True, 104), (True, 120), (True, 136), (True, 176), (True, 208), (True, 216), (True, 232), (True, 256), (True, 288), (True, 48), (True, 40)])
 def test_gpu_ranks_equal_reference_heap_semantics(fused, d):
     """Raw and filtered ranks (counted in the GEMM epilogue when fused, with tensor ops on the stored scores
     otherwise) equal the reference's heap (holE.py:427-472, oracle restatement) fed with the same losses,
-    exact ties included; the losses themselves are within 1e-5 of the fp64 oracle.  embedding_dim 56 ... 232 (every number
-    of 16-column k blocks from 4 to 15, full and ragged last block) run the split-precision sweep, 48 / 40 the fp32
+    exact ties included; the losses themselves are within 1e-5 of the fp64 oracle.  embedding_dim 56 ... 288 (every number
+    of 16-column k blocks from 4 to 15, and 16 and 18, full and ragged last block) run the split-precision sweep, 48 / 40 the fp32
     pipeline with chunk widths 24 / 40."""
     from graphembeddings_amd import evaluate as E
     rng = np.random.default_rng(1)
