@@ -123,10 +123,13 @@ __device__ __forceinline__ void bracket_item(float x, float2 br, int& M, unsigne
       : "vcc");
 }
 
-// the candidate operands of k block kb; src = this lane's 16 bytes of the slice's k block 0, high plane
-__device__ __forceinline__ void h_loadB(HB& b, const _Float16* __restrict__ src, int kb) {
-  b.bh = *reinterpret_cast<const h8*>(src + kb * 2 * kOpHalves);
-  b.bm = *reinterpret_cast<const h8*>(src + kb * 2 * kOpHalves + kOpHalves);
+// the candidate operands of k block kb; off = byte offset in `planes` of this lane's 16 bytes of the slice's k block 0, high
+// plane -- a wave-uniform base and a 32-bit lane offset: the loads take the scalar-base form and the stride over the k
+// blocks costs scalar adds, not two 64-bit vector adds per load
+__device__ __forceinline__ void h_loadB(HB& b, const _Float16* __restrict__ planes, unsigned off, int kb) {
+  const char* base = reinterpret_cast<const char*>(planes);
+  b.bh = *reinterpret_cast<const h8*>(base + (off + (unsigned)(kb * 2 * kOpHalves * 2)));
+  b.bm = *reinterpret_cast<const h8*>(base + (off + (unsigned)((kb * 2 + 1) * kOpHalves * 2)));
 }
 
 // piece i (0..3) of the Q operands of k block `kb`, in the order the MFMAs of that k block first need them: ah0 ah1 am0 am1
@@ -142,7 +145,7 @@ __device__ __forceinline__ void h_opsA(HA& o, const HLds& lds, int wm, int li, i
 // slice `cur` on entry and of the slice `nxt` on exit (a ring of kAhead + 1 register sets; a k block's operands are
 // requested kAhead k blocks -- 18 MFMAs -- before its first MFMA, across the block boundary too).  No barrier.
 template <int KKB>
-__device__ __forceinline__ void h_mfma_loop(const HLds& lds, const _Float16* __restrict__ cur, const _Float16* __restrict__ nxt,
+__device__ __forceinline__ void h_mfma_loop(const HLds& lds, const _Float16* __restrict__ planes, unsigned cur, unsigned nxt,
                                             HB (&B)[kAhead + 1], f32x16 (&acc)[2], int wm, int li, int lh) {
   constexpr int kKB = KKB, kR = kAhead + 1;
 #pragma unroll
@@ -167,8 +170,8 @@ __device__ __forceinline__ void h_mfma_loop(const HLds& lds, const _Float16* __r
         if constexpr (kb + 1 < kKB) h_opsA<KKB>(na, lds, wm, li, lh, kb + 1, p);
       } else if constexpr (p == 4) {                              // the ring slot of k block kb - 1 is free: k block kb + kAhead
         constexpr int kn = kb + kAhead;
-        if constexpr (kn < kKB) h_loadB(B[kn % kR], cur, kn);
-        else h_loadB(B[kn % kR], nxt, kn - kKB);
+        if constexpr (kn < kKB) h_loadB(B[kn % kR], planes, cur, kn);
+        else h_loadB(B[kn % kR], planes, nxt, kn - kKB);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -324,8 +327,8 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     __syncthreads();
 
     // this wave's slices of `planes`: 32 candidates each, slice 4 ct + wn of the share's 128-candidate tiles
-    auto slice_src = [&](int s) -> const _Float16* {              // this lane's 16 bytes of slice s's k block 0 (clamped)
-      return planes + (int64_t)min(s, n_sl - 1) * kSliceHalves + li * 16 + lh * 8;
+    auto slice_src = [&](int s) -> unsigned {                     // byte offset of this lane's 16 bytes of slice s's k block 0 (clamped)
+      return (unsigned)min(s, n_sl - 1) * (unsigned)(kSliceHalves * 2) + (unsigned)(li * 32 + lh * 16);
     };
     auto known_of = [&](int ct, int32_t& k0, int32_t& k1) {
       k0 = k1 = 0;
@@ -354,14 +357,14 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     // true entities (this wave: 32 of them, gathered by position), through the SAME copy of the MFMA loop as the sweep's
     // blocks (a second copy, fetched cold once per row block, took six tiles' time)
     bool diag = MODE != 2;
-    const _Float16* cur = slice_src(s0);
+    unsigned cur = slice_src(s0);
     if constexpr (MODE != 2) {
       const int pos = lds.tP[wn * 32 + li];
       const int pc = pos < 0 ? 0 : pos;
-      cur = planes + (int64_t)(pc >> 5) * kSliceHalves + (pc & 31) * 16 + lh * 8;
+      cur = (unsigned)(pc >> 5) * (unsigned)(kSliceHalves * 2) + (unsigned)((pc & 31) * 32 + lh * 16);
     }
 #pragma unroll
-    for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], cur, j);
+    for (int j = 0; j < kAhead; ++j) h_loadB(Bq[j], planes, cur, j);
     int raw_reg[2][2] = {{0, 0}, {0, 0}};                         // lane r < 32: bits counted for row half*64 + tm*32 + r
 
     // ---- the sweep: behind the true-candidate pass no barrier until the row block is done
@@ -370,14 +373,14 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     while (diag || item < n_items) {
       const int ct = ct0 + (item >> 1), wmi = diag ? wm : (item & 1);
       const int64_t col = (int64_t)(4 * ct + wn) * kSL + li;     // this lane's candidate
-      const _Float16* nxt = slice_src(4 * (ct0 + ((diag ? item : item_next) >> 1)) + wn);
+      const unsigned nxt = slice_src(4 * (ct0 + ((diag ? item : item_next) >> 1)) + wn);
       if (!diag) {
         // (the next block's known-cell range is requested BEFORE the MFMA loop: it is a scalar load, and the wait in front
         // of the epilogue -- for the brackets -- waits for everything on that counter)
         kn0 = kn0_next; kn1 = kn1_next;
         known_of(ct0 + (item_next >> 1), kn0_next, kn1_next);
       }
-      h_mfma_loop<KKB>(lds, cur, nxt, Bq, acc, wmi, li, lh);     // leaves the next block's leading operands in Bq
+      h_mfma_loop<KKB>(lds, planes, cur, nxt, Bq, acc, wmi, li, lh);     // leaves the next block's leading operands in Bq
       cur = nxt;
       if (diag) {
 #pragma unroll
@@ -608,6 +611,7 @@ int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, 
                    int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
   const int64_t n_rb = (B + kRB - 1) / kRB, n_ct = (K + kRB - 1) / kRB;
   if (n_ct > INT32_MAX / 8 || n_rb > INT32_MAX / 8) return GE_ENOTSUP;
+  if (4 * n_ct * (int64_t)KKB * 2 * kOpHalves * 2 >= ((int64_t)1 << 32)) return GE_ENOTSUP;   // (32-bit byte offsets into the planes)
   const int64_t n_tiles = n_rb * n_ct;
   const int64_t grid = std::min<int64_t>(n_tiles, GE_PIPE_GRID_M * (int64_t)f16_cu_count());
   const int32_t* pos_of = reinterpret_cast<const int32_t*>(planes_ws);
