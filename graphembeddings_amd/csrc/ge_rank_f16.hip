@@ -125,7 +125,7 @@ __device__ __forceinline__ void bracket_item(float x, float2 br, int& M, unsigne
 
 // the candidate operands of k block kb; off = byte offset in `planes` of this lane's 16 bytes of the slice's k block 0, high
 // plane -- a wave-uniform base and a 32-bit lane offset: the loads take the scalar-base form and the stride over the k
-// blocks costs scalar adds, not two 64-bit vector adds per load
+// blocks costs one 32-bit add per load, not a 64-bit add with its carry chain
 __device__ __forceinline__ void h_loadB(HB& b, const _Float16* __restrict__ planes, unsigned off, int kb) {
   const char* base = reinterpret_cast<const char*>(planes);
   b.bh = *reinterpret_cast<const h8*>(base + (off + (unsigned)(kb * 2 * kOpHalves * 2)));
