@@ -79,6 +79,7 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
                           max_norm: float = 1.0, fused: bool = None, model: str = "complex", planes=None):
     """Raw and filtered rank of every test triple's true entity among `candidates`, with the
     semantics of holE.py:446-469.  side="tail": candidates replace the tail; "head": the head.
+    known_triples: an [n,3] array, or a KnownIndex built for this side (evaluate_fb15k_style keeps the two it builds).
     Returns (raw_ranks, filtered_ranks) int64 arrays.  The true entity must be a candidate.
     fused (default: whenever the kernel supports embedding_dim): the ranks are counted in the candidate
     GEMM's epilogue (ge_complex_rank_1vK) and no [B,K] score matrix is materialised; otherwise the scores
@@ -108,7 +109,7 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
     # position of every row id in the candidate list (-1: not a candidate)
     pos_of = torch.full((embeddings.shape[0],), -1, dtype=torch.int64, device=dev)
     pos_of[cand64] = torch.arange(cand.numel(), device=dev)
-    index = KnownIndex(known_triples, embeddings.shape[0], side, dev)
+    index = known_triples if isinstance(known_triples, KnownIndex) else KnownIndex(known_triples, embeddings.shape[0], side, dev)
     if batch is None:
         # test rows per call: the stored-scores path holds a [batch, K] fp32 matrix; the fused sweep holds nothing
         # per row, and longer calls amortise its per-row-block set-up (the whole FB15k test set is one call)
@@ -169,10 +170,18 @@ def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True
     planes = None                            # the candidates' fp16 planes: one build for tails and heads
     if d % 8 == 0 and d <= H.rank_max_dim():
         planes = H.RankPlanes(embeddings, torch.as_tensor(cand).to(embeddings.device), model=model)
-    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known, "tail", batch, model=model, planes=planes)
+    # the known-triple indexes (a sort each) are kept on `data`: the train / valid splits do not change between the
+    # evaluations of a training run
+    cache = data.__dict__.setdefault("_known_index_cache", {}) if hasattr(data, "__dict__") else {}
+    def known_index(side):
+        key = (side, str(embeddings.device), N, 0 if known is None else len(known))
+        if key not in cache:
+            cache[key] = KnownIndex(known, N, side, embeddings.device)
+        return cache[key]
+    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known_index("tail"), "tail", batch, model=model, planes=planes)
     raw, fil = [raw_t], [fil_t]
     if both_sides:
-        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known, "head", batch, model=model, planes=planes)
+        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known_index("head"), "head", batch, model=model, planes=planes)
         raw.append(raw_h); fil.append(fil_h)
     out = mrr_and_hits(np.concatenate(raw), np.concatenate(fil))
     if verbose:
