@@ -474,6 +474,191 @@ __global__ __launch_bounds__(kBlock) void score_1vK_tile_kernel(
   }
 }
 
+// The same tile on the f16 MFMA (phase stamps of the fp32 form, 4096 x 256 x 200: row loads 43 % -- the CU's 64 B/clk
+// vector-memory path moving 154 KB --, the 100 fp32 MFMAs per wave 35 %, stashes 17 %, epilogue 12 %).  x * 2^8 = hi + mid
+// with two fp16 values (round toward zero) is exact to 22 bits and q . t = 2^-16 (qh.th + qh.tm + qm.th) + O(2^-22) per
+// product: 3 x 13 f16 MFMAs of 32 cycles instead of 100 fp32 MFMAs of 64.  Both operands are multiplied by their rows'
+// clip scales BEFORE the split (|q sa| <= 2 max_norm^2, |t sb| <= max_norm: inside fp16 for max_norm <= 8 whatever the
+// table holds), so all of a row's loads must have landed before its first stash -- the two-batch overlap of the fp32
+// form is given up for a third of its MFMA time.  LDS: four planes [64 rows][16 KKB + 8 halves].
+typedef _Float16 v1h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 v1h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 v1h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void v1_split(float x0, float x1, v1h2& hi, v1h2& mid) {
+  typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+  const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  hi = __builtin_bit_cast(v1h2, h);
+  const fp16x2 m = __builtin_amdgcn_cvt_pkrtz(x0 - (float)hi.x, x1 - (float)hi.y);
+  mid = __builtin_bit_cast(v1h2, m);
+}
+
+template <int NIT>
+__global__ __launch_bounds__(kBlock) void score_1vK_f16_kernel(
+    const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
+    const int32_t* __restrict__ cand, int64_t K, float max_norm, int apply_sigmoid, int cand_is_head,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = d >> 1, CG = k >> 2;                 // complex column groups of 4 (d % 8 == 0)
+  const int KKB = (d + 15) >> 4, SA = 16 * KKB + 8;  // k blocks of 16 columns; halves per plane row
+  _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+  _Float16* Am = Ah + 64 * SA;
+  _Float16* Bh = Am + 64 * SA;
+  _Float16* Bm = Bh + 64 * SA;
+  float* sA = reinterpret_cast<float*>(Bm + 64 * SA);
+  float* sB = sA + 64;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int srow = 16 * w + (lane & 15), gq = lane >> 4;     // staging: 4 lanes (gq) on 64 contiguous bytes of a row
+  // tiles that share a row block are renumbered onto ONE XCD (score_1vK_tile_kernel)
+  const int gx = gridDim.x, T = gx * (int)gridDim.y;
+  const int L = (int)blockIdx.y * gx + (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int V = xcd * (T >> 3) + min(xcd, T & 7) + slot;
+  const int64_t m0 = (int64_t)(V / gx) * 64, n0 = (int64_t)(V % gx) * 64;
+  int32_t fid = -1, rid = -1, cid = -1;
+  bool abad = false, bbad = false;
+  {
+    const int64_t r = m0 + srow;
+    if (r < B) {
+      fid = hr[2 * r]; rid = hr[2 * r + 1];
+      abad = fid < 0 || fid >= N || rid < 0 || rid >= N;
+    }
+    const int64_t c = n0 + srow;
+    if (c < K) { cid = cand[c]; bbad = cid < 0 || cid >= N; }
+  }
+  const bool aok = fid >= 0 && !abad, bok = cid >= 0 && !bbad;
+  const float* frow = table + (int64_t)(aok ? fid : 0) * d;
+  const float* rrow = table + (int64_t)(aok ? rid : 0) * d;
+  const float* crow = table + (int64_t)(bok ? cid : 0) * d;
+  float4 v[NIT][6];
+  // every load is unconditional (a predicated load makes the compiler serialise the whole batch behind waitcnts):
+  // column groups past the row re-read the last one and are dropped below
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int cc = 4 * min(4 * i + gq, CG - 1);
+    v[i][0] = *reinterpret_cast<const float4*>(frow + cc);
+    v[i][1] = *reinterpret_cast<const float4*>(frow + k + cc);
+    v[i][2] = *reinterpret_cast<const float4*>(rrow + cc);
+    v[i][3] = *reinterpret_cast<const float4*>(rrow + k + cc);
+    v[i][4] = *reinterpret_cast<const float4*>(crow + cc);
+    v[i][5] = *reinterpret_cast<const float4*>(crow + k + cc);
+  }
+  float ssf = 0.f, ssr = 0.f, ssc = 0.f;
+  auto dot4 = [](const float4& a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; };
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    if (4 * i + gq >= CG) continue;
+    ssf += dot4(v[i][0]) + dot4(v[i][1]);
+    ssr += dot4(v[i][2]) + dot4(v[i][3]);
+    ssc += dot4(v[i][4]) + dot4(v[i][5]);
+  }
+  ssf += __shfl_xor(ssf, 16, kWave); ssf += __shfl_xor(ssf, 32, kWave);
+  ssr += __shfl_xor(ssr, 16, kWave); ssr += __shfl_xor(ssr, 32, kWave);
+  ssc += __shfl_xor(ssc, 16, kWave); ssc += __shfl_xor(ssc, 32, kWave);
+  float i0, i1;
+  const float sa = clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1) * 256.f;
+  const float sb = clip_scale(ssc, max_norm, i0) * 256.f;
+  _Float16* ah = Ah + srow * SA;
+  _Float16* am = Am + srow * SA;
+  _Float16* bh = Bh + srow * SA;
+  _Float16* bm = Bm + srow * SA;
+  auto put4 = [](_Float16* hi_p, _Float16* mid_p, float x0, float x1, float x2, float x3) {
+    v1h2 a, b, c, e;
+    v1_split(x0, x1, a, b);
+    v1_split(x2, x3, c, e);
+    *reinterpret_cast<v1h4*>(hi_p) = v1h4{a.x, a.y, c.x, c.y};
+    *reinterpret_cast<v1h4*>(mid_p) = v1h4{b.x, b.y, e.x, e.y};
+  };
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = 4 * i + gq;
+    if (c >= CG) continue;
+    const float fr[4] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w}, fi[4] = {v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+    const float rr[4] = {v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w}, ri[4] = {v[i][3].x, v[i][3].y, v[i][3].z, v[i][3].w};
+    float qre[4], qim[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!cand_is_head) {  // q = h * r
+        qre[q] = fr[q] * rr[q] - fi[q] * ri[q];
+        qim[q] = fr[q] * ri[q] + fi[q] * rr[q];
+      } else {              // Re(h * r * conj(t)) with h the candidate: Q = [Re(r conj t) | -Im(r conj t)]
+        qre[q] = rr[q] * fr[q] + ri[q] * fi[q];
+        qim[q] = -(ri[q] * fr[q] - rr[q] * fi[q]);
+      }
+    }
+    put4(ah + 4 * c, am + 4 * c, qre[0] * sa, qre[1] * sa, qre[2] * sa, qre[3] * sa);
+    put4(ah + k + 4 * c, am + k + 4 * c, qim[0] * sa, qim[1] * sa, qim[2] * sa, qim[3] * sa);
+    put4(bh + 4 * c, bm + 4 * c, v[i][4].x * sb, v[i][4].y * sb, v[i][4].z * sb, v[i][4].w * sb);
+    put4(bh + k + 4 * c, bm + k + 4 * c, v[i][5].x * sb, v[i][5].y * sb, v[i][5].z * sb, v[i][5].w * sb);
+  }
+  if (gq == 0) {
+    for (int c = d; c < 16 * KKB; ++c) { ah[c] = (_Float16)0.f; am[c] = (_Float16)0.f; bh[c] = (_Float16)0.f; bm[c] = (_Float16)0.f; }
+    const float nanv = __builtin_nanf("");
+    sA[srow] = (abad || fid < 0) ? nanv : 1.0f / 65536.f;       // the two 2^8 scales; NaN: bad id / row past B
+    sB[srow] = (bbad || cid < 0) ? nanv : 1.0f;
+  }
+  __syncthreads();
+  f32x16 acc, acc2;                                  // two MFMA chains: the high x high products, the two cross terms
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
+  const int li = lane & 31, lh = lane >> 5;
+  const _Float16* pah = Ah + (wm * 32 + li) * SA + lh * 8;
+  const _Float16* pam = Am + (wm * 32 + li) * SA + lh * 8;
+  const _Float16* pbh = Bh + (wn * 32 + li) * SA + lh * 8;
+  const _Float16* pbm = Bm + (wn * 32 + li) * SA + lh * 8;
+  auto ldo = [&](int kb, v1h8 (&o)[4]) {
+    o[0] = *reinterpret_cast<const v1h8*>(pah + 16 * kb); o[1] = *reinterpret_cast<const v1h8*>(pbh + 16 * kb);
+    o[2] = *reinterpret_cast<const v1h8*>(pam + 16 * kb); o[3] = *reinterpret_cast<const v1h8*>(pbm + 16 * kb);
+  };
+  auto mm3 = [&](const v1h8 (&o)[4]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(o[0], o[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(o[0], o[3], acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(o[2], o[1], acc2, 0, 0, 0);
+  };
+  {
+    // the operands of k block kb + 1 are requested BEFORE the MFMAs of kb and consumed after them (two register sets)
+    v1h8 p0[4], p1[4];
+    ldo(0, p0);
+    for (int kb = 0; kb < KKB; kb += 2) {
+      ldo(min(kb + 1, KKB - 1), p1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm3(p0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kb + 1 < KKB) {
+        ldo(min(kb + 2, KKB - 1), p0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm3(p1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done reading the operands: the planes become the output tile
+  // epilogue through LDS: C layout (col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 lh) -> Cs[row][65-float stride],
+  // then each lane stores 16 contiguous bytes of a row
+  const int cl = wn * 32 + li;
+  const float sbv = sB[cl];                          // (sA / sB sit behind the planes: Cs does not reach them)
+  float* Cs = smem;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rl = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+    const float sv = (acc[q] + acc2[q]) * sA[rl] * sbv;
+    Cs[rl * 65 + cl] = apply_sigmoid ? rank_sigmoid(sv) : sv;
+  }
+  __syncthreads();
+  const bool k4 = (K & 3) == 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int rl = 16 * p + (t >> 4), c4 = 4 * (t & 15);
+    const int64_t row = m0 + rl, col = n0 + c4;
+    if (row >= B) continue;
+    const float* src = Cs + rl * 65 + c4;
+    if (k4 && col + 3 < K) *reinterpret_cast<float4*>(out + row * K + col) = make_float4(src[0], src[1], src[2], src[3]);
+    else
+      for (int j = 0; j < 4; ++j)
+        if (col + j < K) out[row * K + col + j] = src[j];
+  }
+}
+
 int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                              const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
                              int cand_is_head, float* out, hipStream_t st) {
@@ -493,6 +678,22 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
   const int64_t gy = (B + bm - 1) / bm, gx = (K + bm - 1) / bm;
   if (gy > 65535 || gx > 2147483647LL) return GE_ENOTSUP;
   dim3 grid((unsigned)gx, (unsigned)gy);
+  if (!big && d % 8 == 0 && d >= 56 && d <= 224 && max_norm <= 8.f && reinterpret_cast<uintptr_t>(table) % 16 == 0) {
+    // up to a few hundred 64 x 64 tiles, split precision: all of the tile's loads in flight, f16 MFMAs
+    const int kkb = (d + 15) / 16, cgq = (k / 4 + 3) / 4;        // column groups per staging lane
+    const size_t lds16 = sizeof(_Float16) * (size_t)(4 * 64 * (16 * kkb + 8)) + sizeof(float) * 128;
+#define LH(NIT_)                                                                                                          \
+    {                                                                                                                     \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_1vK_f16_kernel<NIT_>),                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+      if (e != hipSuccess) return (int)e;                                                                                 \
+      hipLaunchKernelGGL((score_1vK_f16_kernel<NIT_>), grid, dim3(kBlock), lds16, st, table, N, d, hr, B, cand, K,        \
+                         max_norm, apply_sigmoid, cand_is_head, out);                                                     \
+      return launch_status();                                                                                             \
+    }
+    if (cgq <= 2) LH(2) else if (cgq <= 4) LH(4) else if (cgq <= 6) LH(6) else LH(7)   // (d <= 224: at most 7 groups a lane)
+#undef LH
+  }
   if (!big && d % 8 == 0 && d <= 256 && reinterpret_cast<uintptr_t>(table) % 16 == 0) {
     // up to a few hundred 64 x 64 tiles: the whole tile's loads in flight in two batches, 16-byte LDS traffic
     const size_t lds = sizeof(float4) * (size_t)(4 * (k / 4) * 64) + sizeof(float) * 128;
