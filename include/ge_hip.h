@@ -188,8 +188,10 @@ int ge_bernoulli_corrupt_batch(const int32_t* pos, int64_t B, const int64_t* bh_
 /* --- 1-vs-K candidate scoring (the inference loop of holE.py:564-569: fixed (head, relation)
  * against many tails; also K shared negatives per positive).  hr: [B,2] int32 (fixed entity,
  * relation); cand: [K] int32 candidate entity rows; cand_is_head = 0 scores (fixed, cand_j, rel),
- * 1 scores (cand_j, fixed, rel).  out: [B,K] fp32 row-major.  Runs as an fp32-MFMA GEMM
- * S = Q . T^T with Q = clip(fixed) o clip(rel) (complex product) and T the clipped candidates. */
+ * 1 scores (cand_j, fixed, rel).  out: [B,K] fp32 row-major.  Runs as an MFMA GEMM
+ * S = Q . T^T with Q = clip(fixed) o clip(rel) (complex product) and T the clipped candidates: fp32 MFMA, or --
+ * d % 8 == 0 in 56 ... 224 (small sweeps) / 56 ... 288 (large ones) and max_norm <= 8 -- three f16 MFMAs on operands
+ * split into fp16 high halves and remainders (22 bits), fp32 accumulation; scores within 1e-7 of fp64 either way. */
 int ge_complex_score_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                          const int32_t* cand, int64_t K, float max_norm, int apply_sigmoid,
                          int cand_is_head, float* out, void* stream);
