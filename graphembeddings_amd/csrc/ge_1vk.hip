@@ -533,9 +533,10 @@ __global__ __launch_bounds__(kBlock) void score_1vK_f16_kernel(
   float4 v[NIT][6];
   // every load is unconditional (a predicated load makes the compiler serialise the whole batch behind waitcnts):
   // column groups past the row re-read the last one and are dropped below
+  // (NIT = ceil(CG / 4) exactly, so only the LAST iteration can run past the row: the others address with immediates)
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
-    const int cc = 4 * min(4 * i + gq, CG - 1);
+    const int cc = i + 1 < NIT ? 4 * (4 * i + gq) : 4 * min(4 * i + gq, CG - 1);
     v[i][0] = *reinterpret_cast<const float4*>(frow + cc);
     v[i][1] = *reinterpret_cast<const float4*>(frow + k + cc);
     v[i][2] = *reinterpret_cast<const float4*>(rrow + cc);
@@ -691,7 +692,9 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
                          max_norm, apply_sigmoid, cand_is_head, out);                                                     \
       return launch_status();                                                                                             \
     }
-    if (cgq <= 2) LH(2) else if (cgq <= 4) LH(4) else if (cgq <= 6) LH(6) else LH(7)   // (d <= 224: at most 7 groups a lane)
+    switch (cgq) {                                               // (56 <= d <= 224: 2 ... 7 groups a lane, compiled exactly)
+      case 2: LH(2) case 3: LH(3) case 4: LH(4) case 5: LH(5) case 6: LH(6) default: LH(7)
+    }
 #undef LH
   }
   if (!big && d % 8 == 0 && d <= 256 && reinterpret_cast<uintptr_t>(table) % 16 == 0) {
