@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
 // h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
 // rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
 // Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
-template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER>
+template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER, bool PEER = false>
 __global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
@@ -292,13 +292,24 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
       bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
     }
     if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
+    // Staged rows (the all-to-all schedule) are addressed WITHOUT a branch: with one, the six rows' requests each sat
+    // behind their own branch and `s_waitcnt vmcnt(0)` -- six memory round trips a pair instead of one, 104 us instead of
+    // 87 for the same step (found in the ISA).  The peer-mapped experiment (PEER: the owner's shard read in place, an
+    // integer division per row) is a separate instantiation.
     auto row_ptr = [&](int32_t id) -> const float* {
-      if (SHARD && id >= sg.R) {
-        if (sg.staged) return sg.staged + (int64_t)(id - sg.R) * d;
-        const int32_t o = id / sg.R - 1;                 // peer-mapped: the owner's shard, read in place
-        return sg.peer[o & (kMaxPeers - 1)] + (int64_t)(id - sg.R * (o + 1)) * d;
+      if constexpr (SHARD && PEER) {
+        if (id >= sg.R) {
+          const int32_t o = id / sg.R - 1;
+          return sg.peer[o & (kMaxPeers - 1)] + (int64_t)(id - sg.R * (o + 1)) * d;
+        }
+        return rows + (int64_t)id * d;
+      } else if constexpr (SHARD) {
+        const bool rem = id >= sg.R;
+        const float* base = rem ? sg.staged : rows;
+        return base + (int64_t)(rem ? id - sg.R : id) * d;
+      } else {
+        return rows + (int64_t)id * d;
       }
-      return rows + (int64_t)id * d;
     };
     Row<VEC, NITER> xp[3], xn[3];
 #pragma unroll
@@ -647,9 +658,16 @@ int shard_hinge_grad_launch(float* shard, int32_t d, const float* staged, const 
     for (int i = 0; i < kMaxPeers; ++i) sg.peer[i] = i < n_peers ? peers[i] : nullptr;
   }
 #define CALL(V, L, NI) \
-  hipExtLaunchKernelGGL((complex_hinge_grad_plan_kernel<SP, true, ORDF, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg, order)
-  if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
-  else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
+  hipExtLaunchKernelGGL((complex_hinge_grad_plan_kernel<SP, true, ORDF, V, L, NI, PEERF>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, shard, (int64_t)R, d, nullptr, nullptr, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, shard, sg, order)
+  if (peers) {
+    constexpr bool PEERF = true;
+    if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
+    else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
+  } else {
+    constexpr bool PEERF = false;
+    if (order) { constexpr bool ORDF = true; GE_DISPATCH_SPEC(spectral, s, CALL); }
+    else { constexpr bool ORDF = false; GE_DISPATCH_SPEC(spectral, s, CALL); }
+  }
 #undef CALL
   return launch_status();
 }
