@@ -1,0 +1,25 @@
+"""The rank sweep over 1.2 M candidates (config 4's entity count; planes = 1 GB, far beyond L2 / Infinity Cache):
+counts against the stored-scores definition for a few rows, and the time per sweep."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from graphembeddings_amd import hole as H
+N, d, B = 1_200_018, 200, int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+emb = H.init_embeddings(N, d, seed=1) * 3.0
+g = torch.Generator().manual_seed(2)
+cand = torch.arange(18, N, dtype=torch.int32).cuda()
+hr = torch.stack([torch.randint(18, N, (B,), generator=g), torch.randint(0, 18, (B,), generator=g)], 1).int().cuda()
+tid = torch.randint(18, N, (B,), generator=g).int().cuda()
+planes = H.RankPlanes(emb, cand)
+print("planes MB", planes.buffer.numel() / 1e6)
+nb, nk = H.rank_candidates(emb, hr, tid, cand, planes=planes)[:2]
+sub = slice(0, 16)
+sc = H.score_candidates(emb, hr[sub], cand)
+st = sc.gather(1, (tid[sub].long() - 18).view(-1, 1))
+ref = ((sc < st) | ((sc == st) & (cand.view(1, -1) < tid[sub].view(-1, 1)))).sum(1).int()
+print("first 16 rows equal the stored-scores counts:", bool(torch.equal(nb[sub], ref)), nb[:4].tolist(), ref[:4].tolist())
+ev = H.Events(2); ev.record(0)
+for _ in range(3): H.rank_candidates(emb, hr, tid, cand, planes=planes)
+ev.record(1); torch.cuda.synchronize()
+ms = ev.elapsed_ms(0, 1) / 3
+print(f"{ms:.3f} ms per sweep of {B} x {cand.numel()} = {2.0 * B * cand.numel() * d / (ms * 1e-3) / 1e12:.0f} TFLOP/s fp32-equivalent, planes streamed at {(B // 128) * planes.buffer.numel() / (ms * 1e-3) / 1e12:.2f} TB/s")
