@@ -1,11 +1,12 @@
-"""Event-timed fused rank sweep (FB15k test-set shape, planes built once): python tools/probes/rank_time.py [d]"""
+"""Event-timed fused rank sweep (FB15k test-set shape, planes built once): python tools/probes/rank_time.py [d [table scale]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from graphembeddings_amd import data as D, hole as H
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 inf = D.init_inference_data(D.PACKAGE_FB15K_DIR)
-emb = H.init_embeddings(inf.entity_count, d, seed=3) * 4.0
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+emb = H.init_embeddings(inf.entity_count, d, seed=3) * scale
 test = inf.test_array
 hr = torch.as_tensor(np.stack([test[:, 0], test[:, 2]], 1).astype(np.int32)).cuda()
 tid = torch.as_tensor(test[:, 1].astype(np.int32)).cuda()
