@@ -89,8 +89,11 @@ def run(args, emit=True):
         return out
     timed_grad.pending = False
 
-    CHUNK = 16   # steps per exchange plan (one sort / count exchange / few host syncs per chunk; the plan of
-                 # chunk c+1 is built on a side stream while chunk c trains)
+    CHUNK = 64   # steps per exchange plan (one sort / count exchange / few host syncs per chunk; the plan of
+                 # chunk c+1 is built on a side stream while chunk c trains).  On ONE communicator the plan's count
+                 # exchange queues behind the training chunk's all-to-alls, so the host learns the split sizes only
+                 # when that chunk is done and the device waits for the next chunk's first launch once per chunk:
+                 # long chunks keep that boundary rare (64 steps x 65,536 pairs: 0.5 GB of plan records)
 
     def lr_fn(gs):
         return H.inverse_time_decay(0.1, gs, decay_steps, 0.5)
@@ -111,7 +114,7 @@ def run(args, emit=True):
     # Steady state of a long run: every chunk's plan is built while the chunk before it trains.  The warm-up
     # call therefore plans the timed region's first chunk, and the timed call plans the chunk that would follow
     # it -- the timed region holds K steps and the planning of K steps, none of it on the critical path.
-    warm, timed, after = make_chunks(0, W), make_chunks(W, K), make_chunks(W + K, CHUNK)
+    warm, timed, after = make_chunks(0, W), make_chunks(W, K), make_chunks(W + K, min(CHUNK, K))
     tr.run_pipelined(warm, lr_fn, lookahead=timed[0])
     torch.cuda.synchronize()
     if world > 1:
