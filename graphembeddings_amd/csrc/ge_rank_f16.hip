@@ -480,7 +480,8 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
                   constexpr int q = 4 * g4 + decltype(kc)::value, R32 = (q & 3) + 8 * (q >> 2);
                   if (I & (0x8000u >> q)) {
                     const int rl = wmi * 64 + tm * 32 + R32 + 4 * lh;
-                    const float e = rank_sigmoid(acc[tm][q] * lds.sA[rl]), et = lds.eT[rl];
+                    // (a score inside a bracket belongs to a row WITH a bracket: its sA is the constant, not NaN -- no LDS read)
+                    const float e = rank_sigmoid(acc[tm][q] * (1.0f / (kQScale * kQScale))), et = lds.eT[rl];
                     bool before = e < et;
                     if (e == et) before = (col < K ? cand[col] : -1) < lds.tI[rl];   // equal losses pop in id order
                     if (before) { atomicOr(mrow + R32 + 4 * lh, 1u << li); atomicAdd(&lds.extra[rl], 1); }
