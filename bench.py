@@ -2,7 +2,8 @@
 """bench.py -- scored triples/s of the holE.py hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1 under a launcher: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...;
+   N>1 WITHOUT one: this file starts its own N ranks, graphembeddings_amd/launch.py, before anything touches the GPU)
 
 A "step" is one pass of the hot path over one batch: type-safe corruption of B positives, fused
 gather -> clip -> ComplEx score -> sigmoid -> hinge -> row gradients, sparse SGD scatter-add; it
@@ -352,7 +353,8 @@ def run_single(args):
     traffic = pmc_traffic(kernel_names[dom], tag)
     out = {
         "metric": "scored triples/sec/GPU (d=200)", "value": value, "unit": "scored triples/s",
-        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
+        "n_gpus": 1, "ranks_seen": 1, "backend": "none (one rank: no collective runs)",
+        "steps": K, "warmup": W, "ms_per_step": el / K * 1e3, "higher_is_better": True,
         "timed_calls": reps, "timed_ms": el * reps * 1e3,
         "cold_call": {"value": 2.0 * B * K / cold_el, "ms_per_step": cold_el / K * 1e3,
                       "note": "one K-step call right after a pipeline reset (first prepare launch exposed)"},
@@ -421,7 +423,22 @@ def run_single(args):
 def main():
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle OpenMP workers of the CPU baseline must not spin
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: this process becomes the parent of N ranks.  It has not touched the GPU (nothing imported
+        # so far initialises HIP; counting devices does not) and it never execs -- the ranks are ordinary children that
+        # re-run this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; rank 0 prints the line on our stdout.
+        from graphembeddings_amd import launch
+        try:
+            rc = launch.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__))
+        except (RuntimeError, ValueError) as e:
+            print(json.dumps({"metric": "scored triples/sec/GPU (d=200)", "value": 0.0, "unit": "scored triples/s",
+                              "n_gpus": args.gpus, "ranks_seen": 0, "error": f"{type(e).__name__}: {e}"}), flush=True)
+            sys.exit(2)
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        sys.exit(2)
     sharded = args.gpus > 1 or world > 1 or args.sharded
     if args.batch is None:
         # config[3] names no batch size.  The exchange costs two all-to-alls of (distinct rows x d) per step

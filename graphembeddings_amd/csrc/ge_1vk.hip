@@ -323,7 +323,9 @@ __global__ __launch_bounds__(kBlock) void score_1vK_tile_kernel(
   const int k = d >> 1, CG = k >> 2;                 // complex column groups of 4 (d % 8 == 0)
   float4* As = reinterpret_cast<float4*>(smem);      // [2 CG][64]
   float4* Bs = As + 2 * CG * 64;
-  float* sA = reinterpret_cast<float*>(Bs + 2 * CG * 64);
+  // the clip scales sit behind BOTH the operands and the 64 x 65-float output tile that later aliases them (d < 40:
+  // the tile is the larger of the two), so the epilogue's Cs stores never reach sA / sB while other waves read them
+  float* sA = smem + max(4 * 4 * CG * 64, 64 * 65);
   float* sB = sA + 64;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
@@ -699,7 +701,7 @@ int complex_score_1vK_launch(const float* table, int64_t N, int32_t d, const int
   }
   if (!big && d % 8 == 0 && d <= 256 && reinterpret_cast<uintptr_t>(table) % 16 == 0) {
     // up to a few hundred 64 x 64 tiles: the whole tile's loads in flight in two batches, 16-byte LDS traffic
-    const size_t lds = sizeof(float4) * (size_t)(4 * (k / 4) * 64) + sizeof(float) * 128;
+    const size_t lds = sizeof(float) * std::max<size_t>((size_t)16 * (k / 4) * 64, 64 * 65) + sizeof(float) * 128;
     const int cg = k / 4;
 #define LT(NA, NB)                                                                                                        \
     {                                                                                                                     \

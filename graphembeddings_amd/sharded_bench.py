@@ -137,9 +137,12 @@ def run(args, emit=True):
     tr.k.grad = orig_grad
     ev.close()
     t = torch.tensor([el], device=dev, dtype=torch.float64)
+    seen = torch.ones(1, device=dev, dtype=torch.int32)   # one word per rank, summed: the ranks that really took part
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
     el = float(t.item())
+    ranks_seen = int(seen.item())
     mean_loss = tr.mean_loss(loss)
     if rank == 0:
         kern_ms = float(np.median(grad_ms))
@@ -147,7 +150,11 @@ def run(args, emit=True):
         achieved = alg / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "scored triples/sec/GPU (d=200)", "value": 2.0 * B * world * K / el,
-            "unit": "scored triples/s", "n_gpus": world, "steps": K, "warmup": W,
+            "unit": "scored triples/s", "n_gpus": world, "ranks_seen": ranks_seen,
+            "backend": (backend if world > 1 else "none (one rank: no collective runs)"),
+            "devices": ("all ranks on cuda:0 (GE_SINGLE_DEVICE=1 rehearsal)" if os.environ.get("GE_SINGLE_DEVICE") == "1" and world > 1
+                        else "one device per rank"),
+            "steps": K, "warmup": W,
             "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {n_ent} entities / {args.triples} triples, {args.model} d={d}, "

@@ -334,7 +334,10 @@ def test_gather_and_scatter_rows(H):
 @pytest.mark.parametrize("d,B,K", [(200, 37, 129), (200, 256, 256), (50, 5, 70), (128, 130, 64),
                                    # every instantiation of the split-precision tile kernel (2 ... 7 column groups a lane,
                                    # ragged last group) and the first embedding_dim beyond it (fp32 tile kernel)
-                                   (56, 70, 100), (64, 70, 100), (88, 70, 100), (152, 70, 100), (184, 130, 64), (224, 65, 64), (232, 65, 64)])
+                                   (56, 70, 100), (64, 70, 100), (88, 70, 100), (152, 70, 100), (184, 130, 64), (224, 65, 64), (232, 65, 64),
+                                   # fp32 tile kernel where its 64 x 65 output tile is LARGER than its operands (d < 40:
+                                   # the clip scales must sit behind the tile, not behind the operands), rows 63 / cols 63 used
+                                   (8, 128, 128), (16, 70, 100), (24, 128, 64), (32, 64, 128), (40, 128, 128)])
 @pytest.mark.parametrize("cand_is_head", [False, True])
 def test_score_candidates_matches_per_triple_scores(H, d, B, K, cand_is_head):
     rng = np.random.default_rng(d + B)
