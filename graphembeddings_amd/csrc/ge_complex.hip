@@ -200,16 +200,58 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_kernel(
 }
 
 // ---------------------------------------------------------------- hinge + row gradients, planned steps
-// The same kernel for the steps that come with a plan beyond the direct tags: SHARD (two row stores, the row-sharded
+// The gradient kernel of the steps that come with a plan beyond the direct tags: SHARD (two row stores, the row-sharded
 // step) and / or ORD (pairs walked in relation order, large batches).  The one-tile training step and the single-step
 // API keep the kernel above unchanged: its code is tuned to the 4096-pair step, where every instruction between
 // the id loads and the row loads shows.
-// d(sum_i L_i)/d(raw rows), pre-multiplied by -lr, as IndexedSlices (6 slots per pair:
-// h+, t+, r+, h-, t-, r-).  Through the clip (MinimumGrad routes to the rsqrt branch iff
-// rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw.
-// Written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
+// d(sum_i L_i)/d(raw rows), pre-multiplied by -lr, as IndexedSlices (6 slots per pair: h+, t+, r+, h-, t-, r-; the two
+// negative-side slots of the rows the negative shares with the positive never exist).  Through the clip (MinimumGrad
+// routes to the rsqrt branch iff rsqrt(ss) <= 1/c):  gx = c*(gy*inv - x*(gy.x)*inv^3)  with  gy.x = coef*P_X*s_raw,
+// written per row X as  gx = alpha_X * Graw_X + beta_X * x_X.
+//
+// One (pos, neg) pair = FOUR distinct rows, not six: the negative is the positive with ONE entity replaced
+// (holE.py:104-112, 137-140; the prepared record holds exactly these four sort keys, ge_prep.h).  With F the entity
+// both sides share, V / C the positive's and the negative's other entity and r~ = (Re r, sigma Im r), sigma = +1 when
+// the tail is the replaced column and -1 when the head is,
+//     score(v) = sum Re(w conj v),   w = F r~          (Re<h,r,conj t> with h = F resp. t = F)
+//     d score / d v = w,   d score / d F = conj(r~) v,   d score / d r = (Re, sigma Im) of conj(F) v
+// so both sides share w, the shared rows' loads, norms and clip scales, and the F and r gradients are ONE complex
+// product each of the coefficient-weighted sum of V and C: 32 row registers a lane instead of 48, 6 group reductions
+// instead of 8 (on DPP adds, not LDS permutes), a third fewer vector instructions -- four waves per SIMD (round 3: three).
+// All row loads are unconditional (lanes past the row re-read its last vector and are masked out of the sums): a
+// predicated load puts every row behind its own branch and wait.
+
+// sum over a group of LPT consecutive lanes on the DPP path: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror give
+// every lane of a 16-lane row the row's sum in four v_add_f32_dpp; the two rows of a 32-lane group meet through
+// ds_swizzle (no address register), the two halves of the wave through one permute
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int LPT>
+__device__ __forceinline__ float group_sum_dpp(float v) {
+  static_assert(LPT == 16 || LPT == 32 || LPT == 64, "lane group");
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  v = dpp_add<0x140>(v);    // row_mirror
+  if (LPT >= 32) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));   // lane ^ 16
+  if (LPT >= 64) v += __shfl_xor(v, 32, kWave);
+  return v;
+}
+
+template <int VEC, int LPT, int NITER>
+__device__ __forceinline__ void load_row_clamped(const float* __restrict__ p, int k, int nvec, int sub, Row<VEC, NITER>& R) {
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const int j = min(sub + it * LPT, nvec - 1);
+    load_vec<VEC>(p + j * VEC, R.re[it]);
+    load_vec<VEC>(p + k + j * VEC, R.im[it]);
+  }
+}
+
 template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER, bool PEER = false>
-__global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
+__global__ __launch_bounds__(kBlock, (VEC * NITER <= 4 ? 4 : 2)) void complex_hinge_grad_plan_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
     float* __restrict__ loss, int32_t* __restrict__ grad_idx, float* __restrict__ grad_val,
@@ -226,23 +268,28 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
   constexpr int kSlotDirect = -2;
   constexpr int GPW = kWave / LPT;
   const int lane = threadIdx.x & (kWave - 1), sub = lane % LPT, grp = lane / LPT;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int nB = (int)B;                              // (B <= 2^24 pairs a step, train_fast_ok)
   const int k = d >> 1, nvec = k / VEC;
   const float wscale = 1.0f / (float)d;   // SPEC only: Parseval / correlation-theorem factor
   const float neg_lr = -lr;
+  // which of a lane's vectors are part of the row (the others hold copies of the last one, masked out of every sum)
+  float act[NITER];
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) act[it] = (sub + it * LPT < nvec) ? 1.f : 0.f;
   // ORD: this wave's contiguous run [first, last) of the relation order
-  const int64_t per = ORD ? ((B + nwaves - 1) / nwaves + GPW - 1) / GPW * GPW : 0;
-  const int64_t first = wave * per, last = first + per < B ? first + per : B;
+  const int per = ORD ? ((nB + nwaves - 1) / nwaves + GPW - 1) / GPW * GPW : 0;
+  const int first = wave * per, last = min(first + per, nB);
   float racc_re[NITER][VEC], racc_im[NITER][VEC];   // running relation-row gradient of this lane group's run
 #pragma unroll
   for (int it = 0; it < NITER; ++it)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { racc_re[it][v] = 0.f; racc_im[it][v] = 0.f; }
   int32_t cur_rel = -1;
-  int64_t cur_slot = -1;                              // >= 0: the slot the running sum will be written to
+  int cur_slot = -1;                                  // >= 0: the slot the running sum will be written to
   auto flush = [&]() {
-    float* o = grad_val + cur_slot * d;
+    float* o = grad_val + (int64_t)cur_slot * d;
 #pragma unroll
     for (int it = 0; it < NITER; ++it) {
       const int j = sub + it * LPT;
@@ -256,46 +303,58 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
     if (sub == 0) grad_idx[cur_slot] = cur_rel;
     cur_slot = -1;
   };
-  // the id words of pair g (6: pos + neg triples; SHARD: 3 row sources + the corrupted entity's) and its six tags
-  auto load_ids = [&](int64_t g, int32_t (&raw)[6], int32_t (&tag)[6]) {
+  // The id words of pair g (5: the positive triple + the negative's head and tail -- its relation is the positive's;
+  // SHARD: 3 row sources + the corrupted entity's) and the tags of its slots 0 .. 4 (slot 5 never exists).  A lane group
+  // works on ONE pair, so everything that names the pair is wave-uniform per group: it is read on the SCALAR path
+  // (s_load through the constant address space: the arrays were written by earlier kernels) into SGPRs -- no vector
+  // registers held for the pair ahead, no place in the vector-memory queue, whose wait counter retires loads and
+  // stores in issue order (ids requested before a pair's stores and used after them would make the next pair's row
+  // requests wait for those stores).
+  typedef const __attribute__((address_space(4))) int32_t* kptr_t;
+  auto kld = [](const int32_t* p, int i) -> int32_t { return ((kptr_t)(uintptr_t)p)[i]; };
+  auto load_ids = [&](int g, int32_t (&raw)[5], int32_t (&tag)[5]) {     // g wave-uniform
     if (SHARD) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) raw[c] = sg.pos_src[3 * g + c];
-      raw[3] = sg.neg_src[g]; raw[4] = 0; raw[5] = 0;
+      for (int c = 0; c < 3; ++c) raw[c] = kld(sg.pos_src, 3 * g + c);
+      raw[3] = kld(sg.neg_src, g); raw[4] = 0;
     } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { raw[c] = pos[3 * g + c]; raw[3 + c] = neg[3 * g + c]; }
+      for (int c = 0; c < 3; ++c) raw[c] = kld(pos, 3 * g + c);
+      raw[3] = kld(neg, 3 * g); raw[4] = kld(neg, 3 * g + 1);
     }
-    if (slot_item) {       // one test around all six: per-element tests make the compiler wait after every load
 #pragma unroll
-      for (int c = 0; c < 6; ++c) tag[c] = slot_item[g * 6 + c];
-    } else {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) tag[c] = 0;
-    }
+    for (int c = 0; c < 5; ++c) tag[c] = slot_item ? kld(slot_item, g * 6 + c) : 0;
   };
-  auto body = [&](const int64_t g, const bool live, const int32_t (&raw)[6], const int32_t (&tag)[6]) {
-    int32_t p[3] = {0, 0, 0}, n[3] = {0, 0, 0};
-    bool bad;
+  // lane group j's value of a per-group scalar
+  auto pick = [&](const int32_t (&v)[GPW]) -> int32_t {
+    int32_t r = v[0];
+#pragma unroll
+    for (int j = 1; j < GPW; ++j) r = (grp == j) ? v[j] : r;
+    return r;
+  };
+  auto body = [&](const int g, const bool live, const int32_t (&raw)[5], const int32_t (&tag)[5], auto&& after_loads) {
+    int32_t p0 = 0, p1 = 0, p2 = 0, c = 0;
+    bool hs = false, bad;               // hs: the head is the replaced column
     if (SHARD) {
       int32_t ns = -1;
-      if (live) { p[0] = raw[0]; p[1] = raw[1]; p[2] = raw[2]; ns = raw[3]; }
-      bad = p[0] < 0 || p[1] < 0 || p[2] < 0;
-      n[0] = (ns >= 0 && (ns & 1) == 0) ? (ns >> 1) : p[0];
-      n[1] = (ns >= 0 && (ns & 1) == 1) ? (ns >> 1) : p[1];
-      n[2] = p[2];
+      if (live) { p0 = raw[0]; p1 = raw[1]; p2 = raw[2]; ns = raw[3]; }
+      bad = p0 < 0 || p1 < 0 || p2 < 0;
+      hs = ns >= 0 && (ns & 1) == 0;
+      c = ns >= 0 ? (ns >> 1) : p1;     // ns < 0: the negative IS the positive (hs = false: V = the tail)
     } else {
-      if (live) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { p[c] = raw[c]; n[c] = raw[3 + c]; }
-      }
-      bad = bad3(N, p[0], p[1], p[2]) || bad3(N, n[0], n[1], n[2]);
+      int32_t n0 = 0, n1 = 0;
+      if (live) { p0 = raw[0]; p1 = raw[1]; p2 = raw[2]; n0 = raw[3]; n1 = raw[4]; }
+      bad = bad3(N, p0, p1, p2) || n0 < 0 || n1 < 0 || n0 >= N || n1 >= N;
+      hs = n0 != p0;
+      c = hs ? n0 : n1;
     }
-    if (bad) { p[0] = p[1] = p[2] = n[0] = n[1] = n[2] = 0; }
-    // Staged rows (the all-to-all schedule) are addressed WITHOUT a branch: with one, the six rows' requests each sat
-    // behind their own branch and `s_waitcnt vmcnt(0)` -- six memory round trips a pair instead of one, 104 us instead of
-    // 87 for the same step (found in the ISA).  The peer-mapped experiment (PEER: the owner's shard read in place, an
-    // integer division per row) is a separate instantiation.
+    if (bad) { p0 = p1 = p2 = c = 0; hs = false; }
+    const int32_t idF = hs ? p1 : p0, idV = hs ? p0 : p1;
+    const float sigma = hs ? -1.f : 1.f;
+    // Staged rows (the all-to-all schedule) are addressed WITHOUT a branch: with one, the rows' requests each sat
+    // behind their own branch and `s_waitcnt vmcnt(0)` -- one memory round trip per row instead of one per pair (found in
+    // the ISA in round 3).  The peer-mapped experiment (PEER: the owner's shard read in place, an integer division per
+    // row) is a separate instantiation.
     auto row_ptr = [&](int32_t id) -> const float* {
       if constexpr (SHARD && PEER) {
         if (id >= sg.R) {
@@ -311,130 +370,252 @@ __global__ __launch_bounds__(kBlock) void complex_hinge_grad_plan_kernel(
         return rows + (int64_t)id * d;
       }
     };
-    Row<VEC, NITER> xp[3], xn[3];
+    Row<VEC, NITER> xF, xV, xC, xR;
+    load_row_clamped<VEC, LPT, NITER>(row_ptr(idF), k, nvec, sub, xF);
+    load_row_clamped<VEC, LPT, NITER>(row_ptr(idV), k, nvec, sub, xV);
+    load_row_clamped<VEC, LPT, NITER>(row_ptr(c), k, nvec, sub, xC);
+    load_row_clamped<VEC, LPT, NITER>(row_ptr(p2), k, nvec, sub, xR);
+    __builtin_amdgcn_sched_barrier(0);
+    after_loads();                      // the next pairs' id words are requested behind this pair's rows
+    __builtin_amdgcn_sched_barrier(0);
+    const bool first_el = sub == 0;
+    // forward: w = F r~ once, both scores against it
+    float wre[NITER][VEC], wim[NITER][VEC];
+    float accP = 0.f, accN = 0.f, qF = 0.f, qV = 0.f, qC = 0.f, qR = 0.f;
 #pragma unroll
-    for (int X = 0; X < 3; ++X) load_row_at<VEC, LPT, NITER>(row_ptr(p[X]), k, nvec, sub, xp[X]);
+    for (int it = 0; it < NITER; ++it) {
+      float tP = 0.f, tN = 0.f;
 #pragma unroll
-    for (int X = 0; X < 3; ++X) load_row_at<VEC, LPT, NITER>(row_ptr(n[X]), k, nvec, sub, xn[X]);
-    const SideFwd fp = side_forward<SPEC, VEC, LPT, NITER>(xp[0], xp[1], xp[2], max_norm, sub == 0, wscale);
-    const SideFwd fn = side_forward<SPEC, VEC, LPT, NITER>(xn[0], xn[1], xn[2], max_norm, sub == 0, wscale);
-    const float pre = fp.sig - fn.sig + margin;
+      for (int v = 0; v < VEC; ++v) {
+        const float a = xF.re[it][v], b = xF.im[it][v], cr = xR.re[it][v], di = xR.im[it][v];
+        const float ds = sigma * di;
+        float wr = a * cr - b * ds, wi = a * ds + b * cr;
+        if (SPEC && it == 0 && v == 0 && first_el) { wr = a * cr; wi = b * di; }   // (X_0, X_k): two real dimensions
+        wre[it][v] = wr; wim[it][v] = wi;
+        const float tp = wr * xV.re[it][v] + wi * xV.im[it][v], tn = wr * xC.re[it][v] + wi * xC.im[it][v];
+        if (SPEC && !(it == 0 && v == 0 && first_el)) { tP += 2.f * tp; tN += 2.f * tn; }
+        else { tP += tp; tN += tn; }
+      }
+      accP += act[it] * tP; accN += act[it] * tN;
+    }
+    {
+      // row_sumsq per vector, masked (a lane's clamped copies must not count)
+      auto ssq = [&](const Row<VEC, NITER>& R) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+          float t = 0.f;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float q = R.re[it][v] * R.re[it][v] + R.im[it][v] * R.im[it][v];
+            if (SPEC) t += (it == 0 && v == 0 && first_el) ? q : 2.f * q;
+            else t += q;
+          }
+          s += act[it] * t;
+        }
+        return s;
+      };
+      qF = ssq(xF); qV = ssq(xV); qC = ssq(xC); qR = ssq(xR);
+    }
+    float ssF = group_sum_dpp<LPT>(qF), ssV = group_sum_dpp<LPT>(qV);
+    float ssC = group_sum_dpp<LPT>(qC), ssR = group_sum_dpp<LPT>(qR);
+    float srP = group_sum_dpp<LPT>(accP), srN = group_sum_dpp<LPT>(accN);
+    if (SPEC) { ssF *= wscale; ssV *= wscale; ssC *= wscale; ssR *= wscale; srP *= wscale; srN *= wscale; }
+    float invF, invV, invC, invR;
+    const float scF = clip_scale(ssF, max_norm, invF), scV = clip_scale(ssV, max_norm, invV);
+    const float scC = clip_scale(ssC, max_norm, invC), scR = clip_scale(ssR, max_norm, invR);
+    const float sigP = sigmoidf_dev(srP * (hs ? scV : scF) * (hs ? scF : scV) * scR);     // s_raw * sc_h * sc_t * sc_r
+    const float sigN = sigmoidf_dev(srN * (hs ? scC : scF) * (hs ? scF : scC) * scR);
+    const float pre = sigP - sigN + margin;
     const bool on = live && !bad && (pre >= 0.f);  // MaximumGrad: x >= y
     if (live && sub == 0) loss[g] = bad ? __builtin_nanf("") : fmaxf(pre, 0.f);
-    const float cp = fp.sig * (1.f - fp.sig), cn = -fn.sig * (1.f - fn.sig);
+    const bool same = c == idV;                    // the corrupted entity is the original: one merged row for V
+    const int slot0 = g * 6;
+    const int32_t tagF = hs ? tag[1] : tag[0], tagV = hs ? tag[0] : tag[1], tagR = tag[2], tagC = hs ? tag[3] : tag[4];
+    // local direct (kSlotDirect): row + gradient, applied here; remote direct (SHARD, tag <= -3): the gradient row
+    // itself into the send buffer
+    const bool dirF = slot_item && live && tagF == kSlotDirect, dirV = slot_item && live && tagV == kSlotDirect;
+    const bool dirR = slot_item && live && tagR == kSlotDirect, dirC = slot_item && live && !same && tagC == kSlotDirect;
+    const bool sndF = SHARD && slot_item && live && tagF <= -3, sndV = SHARD && slot_item && live && tagV <= -3;
+    const bool sndR = SHARD && slot_item && live && tagR <= -3, sndC = SHARD && slot_item && live && !same && tagC <= -3;
+    // the relation row of a pair walked in relation order: summed over the run instead of stored per pair
+    const bool accum = ORD && !dirR && !sndR;
+    if (accum && live && cur_slot >= 0 && p2 != cur_rel) flush();
+    if (live && sub == 0) {
+      // (selects, not an array indexed by the column: a dynamically indexed array lives in scratch memory)
+      const int32_t giF = (on && !dirF && !sndF) ? idF : -1, giV = (on && !dirV && !sndV) ? idV : -1;
+      const int32_t giC = (on && !same && !dirC && !sndC) ? c : -1;
+      grad_idx[slot0] = hs ? giV : giF;
+      grad_idx[slot0 + 1] = hs ? giF : giV;
+      grad_idx[slot0 + 2] = (on && !dirR && !sndR && !accum) ? p2 : -1;
+      grad_idx[slot0 + 3] = hs ? giC : -1;
+      grad_idx[slot0 + 4] = hs ? -1 : giC;
+      grad_idx[slot0 + 5] = -1;
+    }
+    if (!on) {
+      // a remote row's only gradient slot is inactive: the owner still receives a row for it -- zeros
+      if (SHARD && (sndF || sndV || sndR || sndC)) {
+        float z[VEC];
 #pragma unroll
-    for (int X = 0; X < 3; ++X) {
-      const bool same = p[X] == n[X];
-      const int64_t rowP = g * 6 + X, rowN = g * 6 + 3 + X;
-      // local direct: row + gradient; remote direct (SHARD, tag <= -3): the gradient row itself into the send buffer
-      const bool dirP = slot_item && live && tag[X] == kSlotDirect;
-      const bool dirN = slot_item && live && !same && tag[3 + X] == kSlotDirect;
-      const bool sndP = SHARD && slot_item && live && tag[X] <= -3;
-      const bool sndN = SHARD && slot_item && live && !same && tag[3 + X] <= -3;
-      // the relation row of a pair walked in relation order: summed over the run instead of stored per pair
-      const bool accum = ORD && X == 2 && same && !dirP && !sndP;
-      if (accum && live && cur_slot >= 0 && p[2] != cur_rel) flush();
-      if (live && sub == 0) {
-        grad_idx[rowP] = (on && !dirP && !sndP && !accum) ? p[X] : -1;
-        grad_idx[rowN] = (on && !same && !dirN && !sndN) ? n[X] : -1;
-      }
-      if (!on) {
-        // a remote row's only gradient slot is inactive: the owner still receives a row for it -- zeros
-        if (SHARD && (sndP || sndN)) {
-          float z[VEC];
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+        for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+        auto zero_row = [&](bool doit, int32_t tg) {
+          if (!doit) return;
+          float* o = sg.gsum + (int64_t)(-3 - tg) * d;
 #pragma unroll
           for (int it = 0; it < NITER; ++it) {
             const int j = sub + it * LPT;
-            if (j >= nvec) continue;
-            if (sndP) { float* o = sg.gsum + (int64_t)(-3 - tag[X]) * d; store_vec<VEC>(o + j * VEC, z); store_vec<VEC>(o + k + j * VEC, z); }
-            if (sndN) { float* o = sg.gsum + (int64_t)(-3 - tag[3 + X]) * d; store_vec<VEC>(o + j * VEC, z); store_vec<VEC>(o + k + j * VEC, z); }
+            if (j < nvec) { store_vec<VEC>(o + j * VEC, z); store_vec<VEC>(o + k + j * VEC, z); }
           }
-        }
-        continue;
+        };
+        zero_row(sndF, tagF); zero_row(sndV, tagV); zero_row(sndR, tagR); zero_row(sndC, tagC);
       }
-      const RowCoef kp = row_coef(cp, fp, X, max_norm, neg_lr);
-      const RowCoef kn = row_coef(cn, fn, X, max_norm, neg_lr);
-      float* gp = dirP ? table_rw + (int64_t)p[X] * d : sndP ? sg.gsum + (int64_t)(-3 - tag[X]) * d : grad_val + rowP * d;
-      float* gn = dirN ? table_rw + (int64_t)n[X] * d : sndN ? sg.gsum + (int64_t)(-3 - tag[3 + X]) * d : grad_val + rowN * d;
+      return;
+    }
+    // coefficients through the clip (row_coef): g_x = alpha * G_raw + beta * x per side
+    const float cp = sigP * (1.f - sigP), cn = -sigN * (1.f - sigN);
+    auto coef = [&](float cf, float P, float inv, float s_raw, float& alpha, float& beta) {
+      const float A = cf * P;
+      const bool active = inv <= 1.0f / max_norm;
+      alpha = neg_lr * (active ? max_norm * A * inv : A);
+      beta = active ? neg_lr * (-max_norm * A * s_raw * inv * inv * inv) : 0.f;
+    };
+    float aFp, bFp, aFn, bFn, aRp, bRp, aRn, bRn, aV, bV, aC, bC;
+    coef(cp, scV * scR, invF, srP, aFp, bFp);
+    coef(cn, scC * scR, invF, srN, aFn, bFn);
+    coef(cp, scF * scV, invR, srP, aRp, bRp);
+    coef(cn, scF * scC, invR, srN, aRn, bRn);
+    coef(cp, scF * scR, invV, srP, aV, bV);
+    coef(cn, scF * scR, invC, srN, aC, bC);
+    const float bF = bFp + bFn, bR = bRp + bRn;
+    if (same) { aV += aC; bV += bC; }
+    const int hsi = hs ? 1 : 0;
+    auto out_ptr = [&](bool dir, bool snd, int32_t tg, int32_t id, int slot) -> float* {
+      return dir ? table_rw + (int64_t)id * d : (SHARD && snd) ? sg.gsum + (int64_t)(-3 - tg) * d : grad_val + (int64_t)slot * d;
+    };
+    // rows V and C: alpha w + beta x
+    {
+      float* o = out_ptr(dirV, sndV, tagV, idV, slot0 + 1 - hsi);
 #pragma unroll
       for (int it = 0; it < NITER; ++it) {
         const int j = sub + it * LPT;
         if (j >= nvec) continue;
-        float pre_[VEC], pim_[VEC], nre_[VEC], nim_[VEC];
+        float ore[VEC], oim[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          float gre, gim;
-          graw<SPEC, VEC, NITER>(X, xp[0], xp[1], xp[2], it, v, sub == 0, gre, gim);
-          pre_[v] = kp.alpha * gre + kp.beta * xp[X].re[it][v];
-          pim_[v] = kp.alpha * gim + kp.beta * xp[X].im[it][v];
-          graw<SPEC, VEC, NITER>(X, xn[0], xn[1], xn[2], it, v, sub == 0, gre, gim);
-          nre_[v] = kn.alpha * gre + kn.beta * xn[X].re[it][v];
-          nim_[v] = kn.alpha * gim + kn.beta * xn[X].im[it][v];
+          ore[v] = aV * wre[it][v] + bV * xV.re[it][v];
+          oim[v] = aV * wim[it][v] + bV * xV.im[it][v];
+          // a direct row: x' = x + (-lr g), the same bits as the apply kernel's 0 + g, then x + sum
+          if (dirV) { ore[v] += xV.re[it][v]; oim[v] += xV.im[it][v]; }
         }
-        if (same) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) { pre_[v] += nre_[v]; pim_[v] += nim_[v]; }
-          if (accum) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) { racc_re[it][v] += pre_[v]; racc_im[it][v] += pim_[v]; }
-            continue;
-          }
-        } else {
-          if (dirN) {   // x' = x + (-lr g): same bits as the apply kernel's 0 + g then x + sum
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) { nre_[v] += xn[X].re[it][v]; nim_[v] += xn[X].im[it][v]; }
-          }
-          store_vec<VEC>(gn + j * VEC, nre_);
-          store_vec<VEC>(gn + k + j * VEC, nim_);
-        }
-        if (dirP) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) { pre_[v] += xp[X].re[it][v]; pim_[v] += xp[X].im[it][v]; }
-        }
-        store_vec<VEC>(gp + j * VEC, pre_);
-        store_vec<VEC>(gp + k + j * VEC, pim_);
+        store_vec<VEC>(o + j * VEC, ore);
+        store_vec<VEC>(o + k + j * VEC, oim);
       }
-      if (accum) { cur_rel = p[2]; cur_slot = rowP; }   // (reached only for hinge-active pairs)
+    }
+    if (!same) {
+      float* o = out_ptr(dirC, sndC, tagC, c, slot0 + 4 - hsi);
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        const int j = sub + it * LPT;
+        if (j >= nvec) continue;
+        float ore[VEC], oim[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          ore[v] = aC * wre[it][v] + bC * xC.re[it][v];
+          oim[v] = aC * wim[it][v] + bC * xC.im[it][v];
+          if (dirC) { ore[v] += xC.re[it][v]; oim[v] += xC.im[it][v]; }
+        }
+        store_vec<VEC>(o + j * VEC, ore);
+        store_vec<VEC>(o + k + j * VEC, oim);
+      }
+    }
+    // row F: conj(r~) (aFp V + aFn C) + bF F
+    {
+      float* o = out_ptr(dirF, sndF, tagF, idF, slot0 + hsi);
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        const int j = sub + it * LPT;
+        if (j >= nvec) continue;
+        float ore[VEC], oim[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float ur = aFp * xV.re[it][v] + aFn * xC.re[it][v], ui = aFp * xV.im[it][v] + aFn * xC.im[it][v];
+          const float cr = xR.re[it][v], di = xR.im[it][v], ds = sigma * di;
+          float gr = cr * ur + ds * ui, gim = cr * ui - ds * ur;
+          if (SPEC && it == 0 && v == 0 && first_el) { gr = cr * ur; gim = di * ui; }
+          ore[v] = gr + bF * xF.re[it][v];
+          oim[v] = gim + bF * xF.im[it][v];
+          if (dirF) { ore[v] += xF.re[it][v]; oim[v] += xF.im[it][v]; }
+        }
+        store_vec<VEC>(o + j * VEC, ore);
+        store_vec<VEC>(o + k + j * VEC, oim);
+      }
+    }
+    // row r: (Re, sigma Im) of conj(F) (aRp V + aRn C), + bR r
+    {
+      float* o = out_ptr(dirR, sndR, tagR, p2, slot0 + 2);
+#pragma unroll
+      for (int it = 0; it < NITER; ++it) {
+        const int j = sub + it * LPT;
+        if (j >= nvec) continue;
+        float ore[VEC], oim[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float ur = aRp * xV.re[it][v] + aRn * xC.re[it][v], ui = aRp * xV.im[it][v] + aRn * xC.im[it][v];
+          const float a = xF.re[it][v], b = xF.im[it][v];
+          float gr = a * ur + b * ui, gim = sigma * (a * ui - b * ur);
+          if (SPEC && it == 0 && v == 0 && first_el) { gr = a * ur; gim = b * ui; }
+          ore[v] = gr + bR * xR.re[it][v];
+          oim[v] = gim + bR * xR.im[it][v];
+          if (dirR) { ore[v] += xR.re[it][v]; oim[v] += xR.im[it][v]; }
+        }
+        if (accum) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { racc_re[it][v] += ore[v]; racc_im[it][v] += oim[v]; }
+        } else {
+          store_vec<VEC>(o + j * VEC, ore);
+          store_vec<VEC>(o + k + j * VEC, oim);
+        }
+      }
+      if (accum) { cur_rel = p2; cur_slot = slot0 + 2; }
     }
   };
-  if constexpr (ORD) {
-    // The run's pair indices come with ONE load per 64 pairs (lane l holds order[first + l]) and every pair's id words
-    // and tags are requested an iteration ahead, while the current pair's rows are in flight: per iteration a wave then
-    // waits for one memory round trip (the rows) instead of three (order -> ids -> rows) -- at 65,536 pairs a wave walks
-    // 4-8 pairs and the chain, not bandwidth, set the kernel's time.  All loads are unconditional (a pair past the run
-    // re-reads pair 0 and is processed as not live).
-    int32_t ord_reg = order[(first + lane < B) ? first + lane : B - 1];
-    int32_t raw[6], tag[6];
-    bool live = first + grp < last;
-    int64_t g = live ? (int64_t)__shfl(ord_reg, grp, kWave) : 0;
-    load_ids(g, raw, tag);
-    for (int64_t base = first; base < last; base += GPW) {
-      const int64_t nb = base + GPW;
-      const int off = (int)((nb - first) & 63);
-      if (off == 0 && nb < last) ord_reg = order[(nb + lane < B) ? nb + lane : B - 1];
-      const int32_t gs = __shfl(ord_reg, off + grp, kWave);
-      const bool live_n = nb + grp < last;
-      const int64_t gn = live_n ? (int64_t)gs : 0;
-      int32_t rawn[6], tagn[6];
-      load_ids(gn, rawn, tagn);
-      body(g, live, raw, tag);
-      g = gn; live = live_n;
+  // Three stages deep, all but the rows on the scalar path: while pair i's rows are in flight, the ids of pair i + 1
+  // (whose index arrived an iteration ago) and the relation-order entry of pair i + 2 are requested; per iteration a wave
+  // waits for one memory round trip (the rows) -- at 65,536 pairs a wave walks 4-8 pairs and the chain, not bandwidth,
+  // set the kernel's time.  Pairs past the run re-read pair 0 and are processed as not live.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int start = ORD ? wave_u * per : wave_u * GPW, stop = ORD ? min(start + per, nB) : nB;
+  const int stride = ORD ? GPW : nwaves * GPW;
+  auto pair_at = [&](int i) -> int32_t {              // the pair at position i of this wave's walk (i wave-uniform)
+    if (i >= stop) return 0;
+    return ORD ? kld(order, i) : i;
+  };
+  int32_t gC[GPW], gN[GPW], rawS[GPW][5], tagS[GPW][5];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) { raw[c] = rawn[c]; tag[c] = tagn[c]; }
+  for (int j = 0; j < GPW; ++j) { gC[j] = pair_at(start + j); gN[j] = pair_at(start + stride + j); }
+#pragma unroll
+  for (int j = 0; j < GPW; ++j) load_ids(gC[j], rawS[j], tagS[j]);
+  for (int base = start; base < stop; base += stride) {
+    const bool live = base + grp < stop;
+    const int g = pick(gC);
+    int32_t raw[5], tag[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      int32_t rv[GPW], tv[GPW];
+#pragma unroll
+      for (int j = 0; j < GPW; ++j) { rv[j] = rawS[j][c]; tv[j] = tagS[j][c]; }
+      raw[c] = pick(rv); tag[c] = pick(tv);
     }
-    if (cur_slot >= 0) flush();
-  } else {
-    for (int64_t base = wave * GPW; base < B; base += nwaves * GPW) {
-      const int64_t g = base + grp;
-      const bool live = g < B;
-      int32_t raw[6] = {0, 0, 0, 0, 0, 0}, tag[6] = {0, 0, 0, 0, 0, 0};
-      if (SHARD) raw[3] = -1;
-      if (live) load_ids(g, raw, tag);     // ids and tags requested together (not after the forward)
-      body(g, live, raw, tag);
-    }
+    body(g, live, raw, tag, [&]() {
+#pragma unroll
+      for (int j = 0; j < GPW; ++j) {
+        gC[j] = gN[j];
+        load_ids(gC[j], rawS[j], tagS[j]);
+        gN[j] = pair_at(base + 2 * stride + j);
+      }
+    });
   }
+  if (ORD && cur_slot >= 0) flush();
 }
 
 // ---------------------------------------------------------------- logistic loss (--log_loss)
