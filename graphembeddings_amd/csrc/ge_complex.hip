@@ -251,6 +251,8 @@ __device__ __forceinline__ void load_row_clamped(const float* __restrict__ p, in
 }
 
 template <bool SPEC, bool SHARD, bool ORD, int VEC, int LPT, int NITER, bool PEER = false>
+// (four waves per SIMD: five -- 96 registers -- spill 13 and run a third slower; 1024 workgroups of longer runs instead of
+// 2048 were 7 % slower)
 __global__ __launch_bounds__(kBlock, (VEC * NITER <= 4 ? 4 : 2)) void complex_hinge_grad_plan_kernel(
     const float* rows, int64_t N, int d, const int32_t* __restrict__ pos,
     const int32_t* __restrict__ neg, int64_t B, float margin, float lr, float max_norm,
@@ -280,7 +282,6 @@ __global__ __launch_bounds__(kBlock, (VEC * NITER <= 4 ? 4 : 2)) void complex_hi
   for (int it = 0; it < NITER; ++it) act[it] = (sub + it * LPT < nvec) ? 1.f : 0.f;
   // ORD: this wave's contiguous run [first, last) of the relation order
   const int per = ORD ? ((nB + nwaves - 1) / nwaves + GPW - 1) / GPW * GPW : 0;
-  const int first = wave * per, last = min(first + per, nB);
   float racc_re[NITER][VEC], racc_im[NITER][VEC];   // running relation-row gradient of this lane group's run
 #pragma unroll
   for (int it = 0; it < NITER; ++it)

@@ -53,9 +53,19 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_keys_kernel(
 
 // ---------------------------------------------------------------- one radix pass
 // hist[(step * radix + digit) * n_sub + tile]
+// `limit` (nullable): the largest row field among the keys, written by the kernel that made them.  A pass whose digits
+// are all zero (shift at or beyond the limit's bit length) is the identity permutation: the count kernel returns and the
+// scatter kernel copies -- the relation-order sort runs over relation ids (18 of them in a Diffbot-like graph, 1,345
+// in FB15k) with the pass count of the TABLE's row range, two of its three passes sorted nothing.
+__device__ __forceinline__ bool pass_is_identity(const unsigned* limit, int shift) {
+  return limit && ((unsigned long long)(*limit) >> (shift - 32)) == 0ull;
+}
+
 __global__ __launch_bounds__(kPrepThreads) void prep_big_hist_kernel(
-    const unsigned long long* __restrict__ src, int P, int n_sub, int shift, int bits, unsigned* __restrict__ hist) {
+    const unsigned long long* __restrict__ src, int P, int n_sub, int shift, int bits, unsigned* __restrict__ hist,
+    const unsigned* __restrict__ limit) {
   __shared__ unsigned cnt[kMaxRadix];
+  if (pass_is_identity(limit, shift)) return;
   const int tid = threadIdx.x, tile = blockIdx.y;
   const int radix = 1 << bits;
   const unsigned dmask = (unsigned)radix - 1u;
@@ -69,29 +79,38 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_hist_kernel(
 
 __global__ __launch_bounds__(kPrepThreads) void prep_big_scatter_kernel(
     const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
-    const unsigned* __restrict__ hist, int P, int n_sub, int shift, int bits) {
+    const unsigned* __restrict__ hist, int P, int n_sub, int shift, int bits, const unsigned* __restrict__ limit) {
   __shared__ unsigned whist[kMaxRadix * kPrepWaves];   // (digit, wave) counters of this tile
   __shared__ unsigned gbase[kMaxRadix];                // first global position of (digit, this tile)
-  __shared__ unsigned wsum[4];
+  __shared__ unsigned dstart[kMaxRadix];               // first position of the digit inside the tile once sorted
+  __shared__ unsigned wsum[4], wsum2[4];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lkeys[];   // the tile, reordered by digit
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6, tile = blockIdx.y;
+  if (pass_is_identity(limit, shift)) {                // (block-uniform)
+    const int64_t o = ((int64_t)blockIdx.x * n_sub + tile) * P;
+    for (int i = tid; i < P; i += kPrepThreads) dst[o + i] = src[o + i];
+    return;
+  }
   const int radix = 1 << bits, R = P / kPrepThreads, seg = kWave * R;
   const unsigned dmask = (unsigned)radix - 1u;
   const unsigned* h = hist + (int64_t)blockIdx.x * radix * n_sub;
   // keys with a smaller digit anywhere + the same digit in earlier tiles
-  unsigned tot = 0, before = 0;
+  unsigned tot = 0, before = 0, mine = 0;
   if (tid < radix)
-    for (int q = 0; q < n_sub; ++q) { const unsigned v = h[tid * n_sub + q]; if (q < tile) before += v; tot += v; }
-  int incl = 0;
+    for (int q = 0; q < n_sub; ++q) { const unsigned v = h[tid * n_sub + q]; if (q < tile) before += v; if (q == tile) mine = v; tot += v; }
+  int incl = 0, incl2 = 0;
   if (tid < kMaxRadix) {
     incl = wave_incl_add((int)tot, lane);
-    if (lane == kWave - 1) wsum[wave] = (unsigned)incl;
+    incl2 = wave_incl_add((int)mine, lane);
+    if (lane == kWave - 1) { wsum[wave] = (unsigned)incl; wsum2[wave] = (unsigned)incl2; }
   }
   for (int i = tid; i < radix * kPrepWaves; i += kPrepThreads) whist[i] = 0;
   __syncthreads();
   if (tid < radix) {
-    unsigned run = (unsigned)incl - tot;
-    for (int w = 0; w < wave; ++w) run += wsum[w];
+    unsigned run = (unsigned)incl - tot, run2 = (unsigned)incl2 - mine;
+    for (int w = 0; w < wave; ++w) { run += wsum[w]; run2 += wsum2[w]; }
     gbase[tid] = run + before;
+    dstart[tid] = run2;
   }
   // ranks inside the tile: wave w owns positions [w*seg, (w+1)*seg), round r holds w*seg + r*64 + lane
   const unsigned long long* kin = src + ((int64_t)blockIdx.x * n_sub + tile) * P;
@@ -126,13 +145,22 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_scatter_kernel(
     for (int w = 0; w < kPrepWaves; ++w) { const unsigned c = whist[tid * kPrepWaves + w]; whist[tid * kPrepWaves + w] = run; run += c; }
   }
   __syncthreads();
-  unsigned long long* out = dst + (int64_t)blockIdx.x * n_sub * P;
+  // The tile is first put in digit order in LDS, then written out in that order: consecutive lanes then write
+  // consecutive keys of one digit's run (about P / radix = 128 keys = 1 KiB per run) instead of 64 scattered 8-byte
+  // stores per wave instruction -- the scattered form moved 0.3 TB/s and was most of the sort's time.
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (r < R) {
       const unsigned dg = (unsigned)(k[r] >> shift) & dmask;
-      out[gbase[dg] + whist[dg * kPrepWaves + wave] + off[r]] = k[r];
+      lkeys[dstart[dg] + whist[dg * kPrepWaves + wave] + off[r]] = k[r];
     }
+  }
+  __syncthreads();
+  unsigned long long* out = dst + (int64_t)blockIdx.x * n_sub * P;
+  for (int i = tid; i < P; i += kPrepThreads) {
+    const unsigned long long kk = lkeys[i];
+    const unsigned dg = (unsigned)(kk >> shift) & dmask;
+    out[gbase[dg] + ((unsigned)i - dstart[dg])] = kk;
   }
 }
 
@@ -289,8 +317,9 @@ __global__ __launch_bounds__(kPrepThreads) void prep_big_items_kernel(
 constexpr int kOrderP = 16384;
 __global__ __launch_bounds__(kPrepThreads) void order_keys_kernel(
     const int32_t* __restrict__ triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t N, int n_o,
-    unsigned long long* __restrict__ keys_out) {
+    unsigned long long* __restrict__ keys_out, unsigned* __restrict__ limit) {
   const int64_t s = blockIdx.x;
+  unsigned rmax = 0;
   const int32_t* pos = T > 0 ? triples + 3 * step_row(first_row, T, B, s0 + s) : triples + s * 3 * B;
   unsigned long long* out = keys_out + (s * n_o + blockIdx.y) * kOrderP;
   for (int i = threadIdx.x; i < kOrderP; i += kPrepThreads) {
@@ -300,9 +329,14 @@ __global__ __launch_bounds__(kPrepThreads) void order_keys_kernel(
       int32_t r = pos[3 * j + 2];
       if (r < 0 || r >= N) r = (int32_t)N;            // invalid pairs last (they contribute nothing anyway)
       k = ((unsigned long long)(uint32_t)r << 32) | (uint32_t)j;
+      rmax = max(rmax, (unsigned)r);
     }
     out[i] = k;
   }
+  // the largest relation id of the chunk: what the sort's passes have to cover (one atomic per wave)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, m, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(limit, rmax);
 }
 
 __global__ __launch_bounds__(kPrepThreads) void order_write_kernel(
@@ -321,23 +355,30 @@ static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * 
 size_t sort_scratch_bytes(int64_t n, int64_t n_sub, int64_t P) {
   const size_t keys = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)n_sub * (size_t)P, 256);
   const size_t hist = align_up_sz(sizeof(unsigned) * (size_t)n * kMaxRadix * (size_t)n_sub, 256);
-  return 2 * keys + hist;
+  return 2 * keys + hist + 256;        // + the `limit` word of a sort whose key kernel reports its largest row field
+}
+static unsigned* sort_scratch_limit(void* scratch, int64_t n, int64_t n_sub, int64_t P) {
+  return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + sort_scratch_bytes(n, n_sub, P) - 256);
 }
 unsigned long long* sort_scratch_keys(void* scratch) { return reinterpret_cast<unsigned long long*>(scratch); }
 
 // stable LSD radix sort of the keys in scratch (as written by a key kernel) on their row field (< n_rows);
 // returns the array that holds the result
-const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st) {
+const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st,
+                                            const unsigned* limit) {
   const SortBits sb = sort_bits_for(n_rows);
   const size_t keys_bytes = align_up_sz(sizeof(unsigned long long) * (size_t)n * (size_t)n_sub * (size_t)P, 256);
   unsigned long long* ka = reinterpret_cast<unsigned long long*>(scratch);
   unsigned long long* kb = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + keys_bytes);
   unsigned* hist = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + 2 * keys_bytes);
   const dim3 grid((unsigned)n, (unsigned)n_sub), block(kPrepThreads);
+  const size_t lds = sizeof(unsigned long long) * (size_t)P;      // the tile in digit order (128 KiB at P = 16,384)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(prep_big_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          140 * 1024) != hipSuccess) return nullptr;
   for (int pass = 0; pass < sb.n_pass; ++pass) {
     const int shift = 32 + pass * sb.bits;
-    hipLaunchKernelGGL(prep_big_hist_kernel, grid, block, 0, st, ka, (int)P, (int)n_sub, shift, sb.bits, hist);
-    hipLaunchKernelGGL(prep_big_scatter_kernel, grid, block, 0, st, ka, kb, hist, (int)P, (int)n_sub, shift, sb.bits);
+    hipLaunchKernelGGL(prep_big_hist_kernel, grid, block, 0, st, ka, (int)P, (int)n_sub, shift, sb.bits, hist, limit);
+    hipLaunchKernelGGL(prep_big_scatter_kernel, grid, block, lds, st, ka, kb, hist, (int)P, (int)n_sub, shift, sb.bits, limit);
     unsigned long long* t = ka; ka = kb; kb = t;
   }
   return ka;
@@ -365,9 +406,12 @@ int items_launch(const unsigned long long* sorted, int64_t n, const TileGeom& G,
 int relation_order_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n, int64_t N,
                           int32_t* out, int64_t stride, int64_t off_order, void* scratch, hipStream_t st) {
   const int n_o = (int)((B + kOrderP - 1) / kOrderP);
+  // (the scratch is the slot-key sort's, sized for more tiles: the limit word sits where THIS sort's geometry puts it)
+  unsigned* limit = sort_scratch_limit(scratch, n, n_o, kOrderP);
+  if (hipMemsetAsync(limit, 0, sizeof(unsigned), st) != hipSuccess) return launch_status();
   hipLaunchKernelGGL(order_keys_kernel, dim3((unsigned)n, (unsigned)n_o), dim3(kPrepThreads), 0, st, triples, T, first_row, B,
-                     s0, N, n_o, sort_scratch_keys(scratch));
-  const unsigned long long* sorted = sort_tiles_launch(scratch, n, n_o, kOrderP, N + 1, st);
+                     s0, N, n_o, sort_scratch_keys(scratch), limit);
+  const unsigned long long* sorted = sort_tiles_launch(scratch, n, n_o, kOrderP, N + 1, st, limit);
   const int gy = (int)std::min<int64_t>((B + kPrepThreads - 1) / kPrepThreads, 64);
   hipLaunchKernelGGL(order_write_kernel, dim3((unsigned)n, (unsigned)gy), dim3(kPrepThreads), 0, st, sorted, n_o, B, stride,
                      off_order, out);
@@ -387,7 +431,7 @@ int prepare_big_launch(const int32_t* triples, int64_t T, int64_t first_row, int
   const dim3 grid((unsigned)n, (unsigned)L.n_sub), block(kPrepThreads);
   hipLaunchKernelGGL(prep_big_keys_kernel, grid, block, 0, st, triples, T, first_row, B, s0, id_to_type, N, type_offsets,
                      n_types, type_ids, seed, global_step0, padded_size, mode, direct, negs, out, sort_scratch_keys(scratch));
-  const unsigned long long* sorted = sort_tiles_launch(scratch, n, L.n_sub, L.P, N, st);
+  const unsigned long long* sorted = sort_tiles_launch(scratch, n, L.n_sub, L.P, N, st, nullptr);
   const int rc = items_launch(sorted, n, geom_of(L), direct, out, nullptr, st);
   if (rc || L.off_order < 0) return rc;
   return relation_order_launch(triples, T, first_row, B, s0, n, N, out, L.stride, L.off_order, scratch, st);

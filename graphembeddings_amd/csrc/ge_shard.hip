@@ -28,7 +28,8 @@ int apply_items_launch(float*, int, const TileGeom&, const int32_t*, const int32
                        hipEvent_t, hipEvent_t);
 size_t sort_scratch_bytes(int64_t n, int64_t n_sub, int64_t P);
 unsigned long long* sort_scratch_keys(void* scratch);
-const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st);
+const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st,
+                                            const unsigned* limit = nullptr);
 int items_launch(const unsigned long long* sorted, int64_t n, const TileGeom& G, int direct, int32_t* out, const ShardOut* so,
                  hipStream_t st);
 int relation_order_launch(const int32_t* triples, int64_t T, int64_t first_row, int64_t B, int64_t s0, int64_t n, int64_t N,

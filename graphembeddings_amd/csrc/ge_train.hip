@@ -297,6 +297,131 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
   }
 }
 
+// The same work item for steps of several tiles (large batches, the row-sharded step), where the kernel is a few hundred
+// thousand short waves whose time is their chain of dependent memory round trips, not their bytes:
+//  * the item header comes on the scalar path (s_load: one item per wave, so it is wave-uniform);
+//  * a row is ONE request per wave -- lane l holds VW consecutive columns (d = 200: 50 lanes x 16 bytes) -- instead of
+//    four 256-byte ones, addressed from scalar registers (v_readlane of the slot + scalar arithmetic);
+//  * the rows of live slots are requested behind wave-uniform branches on the liveness mask, four at a time.
+// Measured at 65,536 pairs on the 960 MB table (round 4, alternated on one box): 47 -> 41 us.  What did NOT help: 8 or
+// 16 rows in flight per wave (45 / 51 us: fewer waves per SIMD), requesting every listed row before the liveness flags
+// are back (one round trip less, dead rows fetched for nothing: 80 -> 91 us in the 16-row form), a quarter or a
+// sixteenth of the workgroups with several items a wave (38-44 us, inside the noise).  Rows split over several items
+// keep the column-per-lane layout: float atomics run at full rate only on 256 contiguous bytes per instruction
+// (16-byte lanes there: 80 us).
+// Summation order and arithmetic are the old kernel's: 0 + g_0 + g_1 + ... in slot order, then row + sum.
+template <int VW, int NJ>
+__global__ __launch_bounds__(kBlock) void apply_rows_kernel(
+    float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
+    int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val, int split,
+    float* __restrict__ out2) {
+  typedef const __attribute__((address_space(4))) int32_t* kptr_t;
+  // row registers a lane: 16 (4 rows of 200 columns in flight per wave; 8 and 16 rows in flight were slower -- 45 / 51 us
+  // against 41: more waves per SIMD hide more than more rows per wave)
+  constexpr int RG0 = 16 / (VW * NJ);
+  constexpr int RG = RG0 > kItemCap ? kItemCap : (RG0 < 2 ? 2 : RG0);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int nwaves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int32_t* subrec = sub0 + (int64_t)blockIdx.y * sub_stride;
+  const kptr_t items = (kptr_t)(uintptr_t)(subrec + off_items);
+  const int32_t* islots = subrec + off_islots;
+  const int n_items = ((kptr_t)(uintptr_t)subrec)[0];
+  int col[NJ];
+  bool ok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { col[j] = VW * (lane + kWave * j); ok[j] = col[j] < d; if (!ok[j]) col[j] = 0; }
+  for (int w = wave; w < n_items; w += nwaves) {
+    const int row = items[2 * w], cm = items[2 * w + 1];
+    int slot_v = (lane < kItemCap) ? islots[w * kItemCap + lane] : -1;
+    const int cnt = cm & 0x3FFFFFFF;
+    const bool multi = (cm >> 30) & 1;
+    const bool away = row >= split;
+    float* dst = away ? out2 + (int64_t)(row - split) * d : table + (int64_t)row * d;
+    if (multi) {
+      // a hot row (> 16 slots: several items): its partial sum is ADDED with float atomics, and those run at full rate
+      // only on 256 contiguous bytes per wave instruction (MI355X_MICROARCH.md): column-per-lane layout, as the
+      // one-tile kernel's
+      constexpr int ND = VW * NJ;
+      const bool act_v = slot_v >= 0 && (!grad_idx || grad_idx[slot_v] >= 0);
+      const unsigned long long lv = __ballot(act_v);
+      if (lv == 0ull) continue;
+      float a[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) a[j] = 0.f;
+      for (int o = 0; o < cnt; o += 4) {
+        float v[4][ND];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (o + q < cnt && ((lv >> (o + q)) & 1ull)) {
+            const float* src = grad_val + (int64_t)__builtin_amdgcn_readlane(slot_v, o + q) * d;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) { const int c = lane + kWave * j; v[q][j] = src[c < d ? c : 0]; }
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (o + q < cnt && ((lv >> (o + q)) & 1ull)) {
+#pragma unroll
+            for (int j = 0; j < ND; ++j) a[j] += v[q][j];
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { const int c = lane + kWave * j; if (c < d) atomic_add_f32(dst + c, a[j]); }
+      continue;
+    }
+    // the table row is fetched now, under the gradient-row loads, not after them
+    float base[NJ][VW];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (!away) load_vec<VW>(dst + col[j], base[j]);
+      else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) base[j][e] = 0.f;
+      }
+    }
+    float acc[NJ][VW];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) acc[j][e] = 0.f;
+    unsigned long long live = 0ull;
+    bool have_live = false;
+    for (int o = 0; o < cnt; o += RG) {
+      float v[RG][NJ][VW];
+      if (!have_live) {
+        const bool act_v = slot_v >= 0 && (!grad_idx || grad_idx[slot_v] >= 0);   // pair was hinge-active
+        live = __ballot(act_v);
+        have_live = true;
+      }
+#pragma unroll
+      for (int q = 0; q < RG; ++q)
+        if (o + q < cnt && ((live >> (o + q)) & 1ull)) {
+          const int sl = __builtin_amdgcn_readlane(slot_v, o + q);
+          const float* src = grad_val + (int64_t)sl * d;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) load_vec<VW>(src + col[j], v[q][j]);
+        }
+#pragma unroll
+      for (int q = 0; q < RG; ++q)
+        if (o + q < cnt && ((live >> (o + q)) & 1ull)) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[j][e] += v[q][j][e];
+        }
+    }
+    if (live == 0ull && !away) continue;              // wave-uniform (a remote row is sent whatever it sums to)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (!ok[j]) continue;
+      float o_[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) o_[e] = base[j][e] + acc[j][e];
+      store_vec<VW>(dst + col[j], o_);
+    }
+  }
+}
+
 int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* step_rec, const int32_t* gidx,
                        const float* gval, int split, float* out2, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int grid = grid_for(G.P, kBlock / kWave);  // at most P items per tile
@@ -306,6 +431,22 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
   {                                                                                                                        \
     if (G.n_sub > 1) hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, true>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
     else hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, false>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
+  }
+  if (G.n_sub > 1) {
+    // steps of several tiles: whole-row requests (see apply_rows_kernel)
+    auto al = [](const void* q, int a) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % a == 0; };
+    const int vw = (d % 4 == 0 && al(table, 16) && al(gval, 16) && al(out2, 16)) ? 4 : (d % 2 == 0 && al(table, 8) && al(gval, 8) && al(out2, 8)) ? 2 : 1;
+    const int njr = (d / vw + kWave - 1) / kWave;
+#define LR(VW, NJ)                                                                                                       \
+    {                                                                                                                    \
+      hipExtLaunchKernelGGL((apply_rows_kernel<VW, NJ>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, \
+                            step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2);     \
+      return launch_status();                                                                                            \
+    }
+    if (vw == 4) { if (njr <= 1) LR(4, 1) else if (njr <= 2) LR(4, 2) else if (njr <= 4) LR(4, 4) }
+    else if (vw == 2) { if (njr <= 1) LR(2, 1) else if (njr <= 2) LR(2, 2) else if (njr <= 4) LR(2, 4) else if (njr <= 8) LR(2, 8) }
+    else { if (njr <= 1) LR(1, 1) else if (njr <= 2) LR(1, 2) else if (njr <= 4) LR(1, 4) else if (njr <= 8) LR(1, 8) else if (njr <= 16) LR(1, 16) }
+#undef LR
   }
   if (nj <= 1) LA(1) else if (nj <= 2) LA(2) else if (nj <= 4) LA(4) else if (nj <= 8) LA(8) else if (nj <= 16) LA(16)
   else return GE_ENOTSUP;
@@ -333,7 +474,7 @@ static int64_t prep_chunk_steps(int64_t B, int64_t negs = 0) {
   // the multi-tile sorts (slot keys, relation order) are ~16 short launches whose latency is the same for 2 steps
   // or 16: a chunk holds enough steps that the sequence (~0.3-0.5 ms) hides behind them -- 16 up to 32,768 units
   // (42 us steps at 16,384), 8 up to 262,144 (19 MB of records each at B = 65,536), 2 beyond
-  const int64_t floor_steps = u <= 32768 ? 16 : u <= 4 * 65536 ? 8 : 2;
+  const int64_t floor_steps = u <= 32768 ? 16 : u <= 4 * 65536 ? 8 : 2;   // (16 and 32 measured at 65,536: no difference)
   return c < floor_steps ? floor_steps : c;
 }
 
@@ -414,6 +555,9 @@ struct Pipeline {
 int pipeline_create(void** out) {
   Pipeline* p = new Pipeline();
   hipError_t e = hipGetDevice(&p->device);
+  // (default priority: the highest one was measured in round 4 and changed nothing -- 126.6 vs 124.7 us per step at
+  // 65,536 pairs, alternated on one box; un-profiled, the host is 8x ahead of the device and the chunk boundary costs no
+  // more than an ordinary kernel boundary)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) {
     e = hipEventCreateWithFlags(&p->prep_done[i], hipEventDisableTiming);

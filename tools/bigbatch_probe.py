@@ -8,6 +8,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+import os
+if os.environ.get("GE_LIB"):       # experiments only (tools/dev/build_variant.py): time a variant build of the library
+    from graphembeddings_amd import _lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["GE_LIB"])
 from graphembeddings_amd import data as D
 from graphembeddings_amd import hole as H
 
@@ -28,9 +32,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tr.run(steps)
+        t_host = (time.perf_counter() - t0) / steps      # the host's enqueue time: close to us_per_step = launch-bound
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
-        out = {"B": B, "us_per_step": el * 1e6, "scored_per_s": 2 * B / el,
+        out = {"B": B, "us_per_step": el * 1e6, "host_enqueue_us_per_step": t_host * 1e6, "scored_per_s": 2 * B / el,
                "step_alg_frac_of_8TBs": (72 * d + 28) * B / el / 8e12}
         for kern, name in ((1, "grad_us"), (2, "apply_us")):
             ev = H.Events(2 * steps)
