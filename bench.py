@@ -45,6 +45,8 @@ def parse():
                     help="skip the HBM-bound leg of the train step (960 MB table, 65,536 pairs per step)")
     ap.add_argument("--no-rank-roofline", action="store_true",
                     help="skip the MFMA-bound leg (the link-prediction rank sweep at the FB15k test set's shape)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the legs for BASELINE configs 3 (HolE d=200 B=4096 step) and 5 (4096 x 256 x 200 1-vs-K contraction)")
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="skip the 1-GPU run of the row-sharded config[3] workload that the N>1 lines are comparable to")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -144,7 +146,7 @@ def train_step_hbm_roofline(d, B=SHARDED_BATCH, n_entities=1_200_000, steps=48):
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
     kern = {}
-    for k, name in ((1, "complex_hinge_grad_plan_kernel"), (2, "apply_sorted_kernel")):
+    for k, name in ((1, "complex_hinge_grad_plan_kernel"), (2, "apply_rows_kernel")):
         ev = H.Events(2 * steps)
         tr.run(steps, events=ev.handles, ev_kernel=k)
         torch.cuda.synchronize()
@@ -155,18 +157,28 @@ def train_step_hbm_roofline(d, B=SHARDED_BATCH, n_entities=1_200_000, steps=48):
     del emb, tr, dtri
     alg = {"step": (72 * d + 28) * B, "complex_hinge_grad_plan_kernel": (24 * d + 28) * B}
     traffic = {k: pmc_traffic(k, f"synthetic_d{d}_b{B}") for k in kern}
+    # Two fractions, side by side.  `useful_bytes_frac`: SURVEY.md 8(d)'s ALGORITHMIC bytes of a step (72d+28 per pair: six
+    # rows read, six read-modify-written) over the step's time -- credit for bytes the path does not move at all (a pair's
+    # negative shares two rows with its positive, relation rows are summed in registers, sole-slot rows are updated by the
+    # producing pair).  `achieved` / `frac`: the bytes the two kernels REALLY move per step (committed rocprofv3 PMC
+    # summary of this very workload) over the step's time -- DRAM utilisation, the figure a roofline is about.
+    moved = sum(t["hbm_bytes_per_launch"] for t in traffic.values() if t) if all(traffic.values()) else None
     return {"workload": f"synthetic {n_entities} entities, complex d={d}, batch={B}, native loop (ge_train_steps), 1 GPU",
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "table_mb": round(data.entity_count * d * 4 / 1e6, 1),
             "ms_per_step": el * 1e3, "scored_triples_per_s": 2.0 * B / el,
-            "achieved": alg["step"] / el / 1e9, "frac": alg["step"] / el / 1e9 / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_step": alg["step"],
+            "achieved": (moved / el / 1e9) if moved else None, "frac": (moved / el / 1e9 / HBM_PEAK_GBS) if moved else None,
+            "traffic": moved, "traffic_source": next((t["source"] for t in traffic.values() if t), None),
+            "useful_bytes_per_step": alg["step"], "useful_GBs": alg["step"] / el / 1e9,
+            "useful_bytes_frac": alg["step"] / el / 1e9 / HBM_PEAK_GBS,
             # per kernel: its time and its measured HBM traffic (committed PMC summary).  An algorithmic figure is given
             # for the gradient kernel only: the 48d of the update's read-modify-writes are mostly done inside it (sole-slot
             # rows) or merged before the apply kernel runs, so a per-kernel share of them would be arbitrary.
             "kernels": {k: dict({"kernel_ms": v, "traffic": traffic[k]["hbm_bytes_per_launch"] if traffic[k] else None,
                                  "traffic_source": traffic[k]["source"] if traffic[k] else None},
-                                **({"algorithmic_bytes_per_launch": alg[k], "achieved": alg[k] / (v * 1e-3) / 1e9,
-                                    "frac": alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} if k in alg else {}))
+                                **({"measured_GBs": traffic[k]["hbm_bytes_per_launch"] / (v * 1e-3) / 1e9,
+                                    "measured_frac": traffic[k]["hbm_bytes_per_launch"] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} if traffic[k] else {}),
+                                **({"algorithmic_bytes_per_launch": alg[k], "useful_GBs": alg[k] / (v * 1e-3) / 1e9,
+                                    "useful_bytes_frac": alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} if k in alg else {}))
                         for k, v in kern.items()},
             "final_mean_hinge": round(loss, 6)}
 
@@ -206,6 +218,91 @@ def rank_sweep_mfma_roofline(d, n_rows=59_071, n_entities=16_296, n_relations=1_
             "frac": executed / (ms * 1e-3) / 1e12 / peak, "executed_flop_per_launch": executed,
             "fp32_equivalent_tflops": 2.0 * n_rows * K * d / (ms * 1e-3) / 1e12,
             "mean_rank": float(nb.float().mean()) + 1.0}
+
+
+def config3_hole_step(d, B=4096, steps=400, warmup=64):
+    """BASELINE config 3: FB15k-shaped, HolE (README.md:42: r . (h correlated with t)) d=200, batch 4096, 1 neg/pos, one GPU.
+    The table is carried in the frequency domain for the whole run (what train.py does: ge_hole_to_spectral once, then
+    the ComplEx-shaped pair of kernels with Hermitian weights), so a step is prepare (side stream) + gradient + update,
+    like config 2's.  Reported: ms per step over `steps` steps in back-to-back native calls, scored triples/s, each
+    kernel's own time (HIP events on its dispatch) and the dominant one's algorithmic bytes against the HBM peak."""
+    import torch
+    from graphembeddings_amd import data as D
+    from graphembeddings_amd import hole as H
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    triples = D.synthetic_fb15k_triples(fb, n_triples=483142, seed=0)
+    emb = H.init_embeddings(fb.entity_count, d, seed=0)
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    dtri = torch.as_tensor(triples).cuda()
+    tr = H.Trainer(emb, dtri, tt, B, margin=0.2, learning_rate=0.1, decay_steps=32.0 * (len(triples) // B), decay_rate=0.5,
+                   model="hole", seed=0, spectral_resident=True)
+    tr.reshuffle(torch.Generator(device="cuda").manual_seed(0))
+    tr.run(warmup)
+    torch.cuda.synchronize()
+    call = 20                                             # steps per native call, as the driver's --steps
+    t0 = time.perf_counter()
+    for _ in range(steps // call):
+        tr.run(call)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / (steps // call * call)
+    kern = {}
+    probe = 32
+    for k, name in ((1, "complex_hinge_grad_kernel<SPEC>"), (2, "apply_sorted_kernel")):
+        ev = H.Events(2 * probe)
+        tr.run(probe, events=ev.handles, ev_kernel=k)
+        torch.cuda.synchronize()
+        kern[name] = float(np.median([ev.elapsed_ms(2 * i, 2 * i + 1) for i in range(probe)]))
+        ev.close()
+    loss = float(tr.last_loss.mean())
+    tr.close()
+    dom = max(kern, key=kern.get)
+    alg = algorithmic_bytes(1 if "grad" in dom else 2, B, d)
+    return {"workload": f"FB15k-shaped, HolE d={d} (table resident in the frequency domain), batch={B}, 1 neg/pos, 1 GPU",
+            "ms_per_step": el * 1e3, "scored_triples_per_s": 2.0 * B / el, "steps": steps // call * call,
+            "kernels_ms": {k: round(v, 5) for k, v in kern.items()}, "dominant_kernel": dom, "bound": "hbm",
+            "algorithmic_bytes_per_launch": alg, "achieved": alg / (kern[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": alg / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "final_mean_hinge": round(loss, 6)}
+
+
+def config5_score_1vK(d, B=4096, K=256, calls=400):
+    """BASELINE config 5 at its own shape: FB15k-shaped table, 4096 (entity, relation) rows against 256 shared negatives
+    as ONE (B x d) . (d x K) contraction on the matrix cores (ge_complex_score_1vK: clip scales, sigmoid and the [B,K]
+    store in the epilogue).  us per call over `calls` back-to-back calls into a preallocated output, flop = 2 B K d."""
+    import torch
+    from graphembeddings_amd import _lib
+    from graphembeddings_amd import hole as H
+    N, R = 16296, 1345
+    emb = H.init_embeddings(N, d, seed=0) * 4.0
+    g = torch.Generator().manual_seed(0)
+    hr = torch.stack([torch.randint(R, N, (B,), generator=g), torch.randint(0, R, (B,), generator=g)], 1).int().cuda()
+    cand = torch.randint(R, N, (K,), generator=g).int().cuda()
+    out = torch.empty(B, K, device="cuda")
+    st = H._stream()
+
+    def one():
+        _lib.call("ge_complex_score_1vK", emb.data_ptr(), N, d, hr.data_ptr(), B, cand.data_ptr(), K, 1.0, 1, 0, out.data_ptr(), st)
+    for _ in range(8):
+        one()
+    torch.cuda.synchronize()
+    ev = H.Events(2)
+    ev.record(0)
+    for _ in range(calls):
+        one()
+    ev.record(1)
+    torch.cuda.synchronize()
+    us = ev.elapsed_ms(0, 1) / calls * 1e3
+    ev.close()
+    ref = H.evaluate_triples(torch.stack([hr[:64, 0], cand[:64], hr[:64, 1]], 1), emb)[:, 0]
+    err = float((out[:64, :64].diagonal() - ref).abs().max())
+    flop = 2.0 * B * K * d
+    split = d % 8 == 0 and 56 <= d <= 224
+    return {"workload": f"FB15k-shaped table, {B} (entity, relation) rows x {K} shared negatives, complex d={d}: one [B,d] x [d,K] contraction",
+            "kernel": "score_1vK_f16_kernel (split precision: 3 f16 MFMAs per product, fp32-class accuracy)" if split else "score_1vK_tile_kernel (fp32 MFMA)",
+            "us_per_call": us, "calls": calls, "scored_triples_per_s": B * K / (us * 1e-6), "flop_per_call": flop,
+            "bound": "mfma (in practice launch + two dependent memory round trips: a 0.4 GFLOP problem)",
+            "achieved": flop / (us * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s (fp32-equivalent against the fp32 MFMA peak)",
+            "frac": flop / (us * 1e-6) / 1e12 / 157.3, "max_abs_diff_vs_per_triple_kernel": err}
 
 
 def cpu_baseline_fb15k(fb, type_arrays, d, B, seconds):
@@ -270,7 +367,7 @@ def run_single(args):
     if workload == "fb15k":
         fb = D.fb15k_shape()
         arrays = fb.type_arrays()
-        triples = D.synthetic_fb15k_triples(fb, n_triples=483142, seed=0, zipf_s=float(os.environ.get("GE_BENCH_ZIPF", "1.0")))
+        triples = D.synthetic_fb15k_triples(fb, n_triples=483142, seed=0)
         n_rows = fb.entity_count
         name = f"FB15k-shaped (16,296 rows, 815 types, 483,142 synthetic train triples), {args.model} d={d}, batch={B}, 1 neg/pos, fused gather+score+hinge+grad + scatter SGD"
     else:
@@ -398,6 +495,12 @@ def run_single(args):
             out["rank_sweep_mfma_roofline"] = rank_sweep_mfma_roofline(d)
         except Exception as e:  # never lose the headline line to an auxiliary leg
             out["rank_sweep_mfma_roofline"] = {"error": f"{type(e).__name__}: {e}"}
+    if not args.no_extra_configs and args.workload == "auto" and args.model == "complex":
+        for key, fn in (("config3_hole_step", config3_hole_step), ("config5_score_1vK", config5_score_1vK)):
+            try:
+                out[key] = fn(d)
+            except Exception as e:  # never lose the headline line to an auxiliary leg
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
     if not args.no_cpu_baseline and workload == "fb15k":
         out["cpu_baseline"] = cpu_baseline_fb15k(fb, arrays, d, B, args.cpu_seconds)
     elif not args.no_cpu_baseline:

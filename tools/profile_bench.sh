@@ -7,23 +7,23 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline > "$OUT/${TAG}_trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline --no-extra-configs > "$OUT/${TAG}_trace.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_$C" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline > "$OUT/${TAG}_pmc_$C.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_$C" -- python3 "$ROOT/bench.py" "$@" --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline --no-extra-configs > "$OUT/${TAG}_pmc_$C.log" 2>&1
 done
 python3 - "$OUT" "$TAG" "$*" <<'PY'
 import csv, glob, json, re, sys, collections
 out, tag, args = sys.argv[1], sys.argv[2], sys.argv[3]
 stats = glob.glob(f"{out}/{tag}_trace/*/*_kernel_stats.csv")
 with open(f"{out}/{tag}_kernel_stats.csv", "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {args} --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py {args} --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline --no-extra-configs\n")
     if stats:
         for i, row in enumerate(csv.reader(open(stats[0]))):
             row[0] = re.sub(r"\(.*", "", row[0])[:100]
             if i == 0 or "ge::" in row[0]:
                 f.write(",".join(row) + "\n")
 bench_line = [l for l in open(f"{out}/{tag}_trace.log") if l.startswith("{")]
-pmc = {"_command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py {args} --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline (one pass per counter)",
+pmc = {"_command": f"rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py {args} --no-cpu-baseline --no-scaling-base --no-hbm-roofline --no-rank-roofline --no-extra-configs (one pass per counter)",
        "_units": "counter values in KB per launch (mean over launches); FETCH_SIZE doubled in hbm_bytes_corrected per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
 agg = collections.defaultdict(dict)
 for C in ("FETCH_SIZE", "WRITE_SIZE"):

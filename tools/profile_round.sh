@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box: everything profiles/ holds for one round, under gpurun_out/ with the round tag.
-# Usage: bash tools/profile_round.sh r03
+# Usage: bash tools/profile_round.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -16,6 +16,10 @@ bash tools/profile_bench.sh ${TAG}_fb15k_d200_b4096 --no-score-roofline > "$OUT/
 echo "profile fb15k done"
 bash tools/profile_bench.sh ${TAG}_synthetic_d200_b65536 --workload synthetic --batch 65536 --steps 64 --warmup 16 --no-score-roofline > "$OUT/${TAG}_prof_synth.log" 2>&1
 echo "profile synthetic done"
+bash tools/profile_bench.sh ${TAG}_fb15k_hole_d200_b4096 --model hole --no-score-roofline > "$OUT/${TAG}_prof_hole.log" 2>&1
+echo "profile hole (config 3) done"
+bash tools/profile_score.sh ${TAG} > "$OUT/${TAG}_prof_score.log" 2>&1
+echo "profile score kernel done"
 ( cd /tmp && export TMPDIR=/tmp && B=4096 K=256 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_onevk_trace" -- python3 "$ROOT/tools/onevk_only.py" > "$OUT/${TAG}_onevk.log" 2>&1 )
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys
@@ -33,6 +37,7 @@ bash tools/profile_rank.sh ${TAG} > "$OUT/${TAG}_prof_rank.log" 2>&1
 echo "rank done"
 timeout -k 10 300 python tools/rank_bench.py > "$OUT/${TAG}_rank_bench.json" 2>"$OUT/${TAG}_rank_bench.err"
 echo "rank bench done"
-GE_DIST_BACKEND=gloo GE_SINGLE_DEVICE=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 16 --warmup 16 --batch 16384 > "$OUT/${TAG}_gloo2_rehearsal.log" 2>&1
+# no launcher: bench.py starts its own two ranks (graphembeddings_amd/launch.py); both on this box's one GPU, collectives through gloo
+GE_DIST_BACKEND=gloo GE_SINGLE_DEVICE=1 timeout -k 10 400 python bench.py --gpus 2 --steps 16 --warmup 16 --batch 16384 > "$OUT/${TAG}_gloo2_rehearsal.log" 2>&1
 tail -1 "$OUT/${TAG}_gloo2_rehearsal.log" | cut -c1-300
 echo "all done"
