@@ -52,6 +52,7 @@ SYMBOLS = {
     "ge_rank_planes_bytes": (_i64, [_i64, _i32, _i64]),
     "ge_rank_planes": (C.c_int, [_p, _i64, _i32, _p, _i64, _f, C.c_int, _p, _p]),
     "ge_rank_1vK_planes": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "ge_rank_1vK_vs_loss": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _p, _p, _i64, _f, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p]),
     "ge_train_workspace_bytes": (_sz, [_i64, _i32]),
     "ge_train_pipeline_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ge_train_pipeline_reset": (C.c_int, [_p]),
@@ -116,7 +117,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI and the header diverge
             fn.restype = res
             fn.argtypes = args
-        if lib.ge_version() < 300:
+        if lib.ge_version() < 320:
             raise RuntimeError("libge_hip.so is older than the Python host expects")
         _lib = lib
     return _lib

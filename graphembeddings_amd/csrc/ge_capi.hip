@@ -12,7 +12,7 @@ int select_rows_launch(const int32_t*, int64_t, int64_t, uint64_t, uint64_t, int
 int mean_pocket_launch(const float*, int64_t, float*, float*, int32_t*, hipStream_t);
 int copy_if_launch(const float*, float*, int64_t, const int32_t*, hipStream_t);
 int rank_max_dim();
-int complex_rank_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float, int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, const void*, hipStream_t);
+int complex_rank_1vK_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, const int32_t*, const int32_t*, int64_t, float, int, const int32_t*, const uint16_t*, int32_t*, int32_t*, float*, float*, int, const void*, hipStream_t, int vs_loss = 0);
 int64_t rank_planes_bytes(int64_t, int32_t, int64_t);
 int known_cells_launch(int, const int64_t*, const int64_t*, int64_t, const int64_t*, const int64_t*, int64_t, const int64_t*, int64_t, int64_t, int32_t*, int32_t*, uint16_t*, hipStream_t);
 int rank_planes_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, float, int, void*, hipStream_t);
@@ -314,6 +314,28 @@ int ge_rank_1vK_planes(const float* table, int64_t N, int32_t d, const int32_t* 
   if (e != hipSuccess) return (int)e;
   return complex_rank_1vK_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,
                                  n_before, n_known_before, true_loss, scores_out, model == GE_MODEL_HOLE_SPECTRAL, planes, st);
+}
+
+int ge_rank_1vK_vs_loss(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* ref_id,
+                        const float* ref_loss, const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head,
+                        const int32_t* known_off, const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before,
+                        const void* planes, void* stream) {
+  if (B < 0 || K < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm)) return GE_EINVAL;
+  if (model != GE_MODEL_COMPLEX && model != GE_MODEL_HOLE_SPECTRAL) return model == GE_MODEL_HOLE || model == GE_MODEL_HOLE_DIRECT ? GE_ENOTSUP : GE_EINVAL;
+  if (B > 0 && (!hr || !ref_id || !ref_loss || !n_before || !n_known_before)) return GE_EINVAL;
+  if (B > 0 && K > 0 && !cand) return GE_EINVAL;
+  if ((known_off == nullptr) != (known_rc == nullptr)) return GE_EINVAL;
+  if (planes && (rank_planes_bytes(N, d, K) == 0 || reinterpret_cast<uintptr_t>(planes) % 256 != 0)) return GE_EINVAL;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(n_before, 0, sizeof(int32_t) * (size_t)B, st);
+  if (e == hipSuccess) e = hipMemsetAsync(n_known_before, 0, sizeof(int32_t) * (size_t)B, st);
+  if (e != hipSuccess) return (int)e;
+  if (K == 0) return 0;
+  // (the launchers take the losses through their true_loss argument, which this mode only reads)
+  return complex_rank_1vK_launch(table, N, d, hr, B, ref_id, cand, K, max_norm, cand_is_head, known_off, known_rc, n_before,
+                                 n_known_before, const_cast<float*>(ref_loss), nullptr, model == GE_MODEL_HOLE_SPECTRAL, planes, st,
+                                 /*vs_loss=*/1);
 }
 
 int ge_rank_1vK(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
-    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
-    float* __restrict__ scores_out, int lda, int spec) {
+    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* true_loss,
+    float* __restrict__ scores_out, int lda, int spec, int vs_loss) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RankLds lds;
   lds.A = smem;
@@ -284,7 +284,17 @@ __global__ __launch_bounds__(kBlock) void rank_1vK_kernel(
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int q = 0; q < 16; ++q) et[tm][q] = lds.eT[wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh];
-    if (true_loss && blockIdx.x == 0 && t < kRB && m0 + t < B) true_loss[m0 + t] = lds.eT[t];
+    if (vs_loss) {
+      // ranking against GIVEN losses (ge_rank_1vK_vs_loss): the tile above ran on whatever rows true_id names (the
+      // tie-break ids; any row, or none) and is overruled
+      __syncthreads();
+      if (t < kRB) lds.eT[t] = m0 + t < B ? true_loss[m0 + t] : __builtin_nanf("");
+      __syncthreads();
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) et[tm][q] = lds.eT[wm * 64 + tm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh];
+    } else if (true_loss && blockIdx.x == 0 && t < kRB && m0 + t < B) true_loss[m0 + t] = lds.eT[t];
   }
   int raw_reg = 0;
 
@@ -356,14 +366,15 @@ constexpr int kRankMaxDimF32 = 232;  // the fp32 kernels: Q (128 x (d+1) floats)
 int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B,
                             const int32_t* true_id, const int32_t* cand, int64_t K, float max_norm, int cand_is_head,
                             const int32_t* known_off, const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt,
-                            float* true_loss, float* scores_out, int spec, const void* planes_ws, hipStream_t st) {
+                            float* true_loss, float* scores_out, int spec, const void* planes_ws, hipStream_t st, int vs_loss) {
+  // vs_loss: true_loss is an INPUT -- the loss every candidate of row i is ranked against -- and true_id the tie-break id
   if (d <= 0 || (d & 7)) return (d <= 0 || (d & 1)) ? GE_EINVAL : GE_ENOTSUP;   // 16-byte candidate loads, 8-float tail
   if (d > rank_max_dim()) return GE_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
   if (B == 0 || K == 0) return 0;
   {  // embedding_dim a multiple of 40, 32 or 24: the software-pipelined kernel (ge_rank_pipe.hip)
     const int rc = rank_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc,
-                                    raw_cnt, skip_cnt, true_loss, scores_out, spec, planes_ws, st);
+                                    raw_cnt, skip_cnt, true_loss, scores_out, spec, planes_ws, st, vs_loss);
     if (rc != GE_ENOTSUP) return rc;
   }
   if (d > kRankMaxDimF32) return GE_ENOTSUP;                    // (233 ... 288 with max_norm > 8)
@@ -379,7 +390,7 @@ int complex_rank_1vK_launch(const float* table, int64_t N, int32_t d, const int3
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(rank_1vK_kernel, dim3((unsigned)splits, (unsigned)n_rb), dim3(kBlock), lds, st, table, N, d, hr, B,
                      true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt, skip_cnt, true_loss,
-                     scores_out, d + 1, spec);
+                     scores_out, d + 1, spec, vs_loss);
   return launch_status();
 }
 

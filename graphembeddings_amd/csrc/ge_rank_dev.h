@@ -21,7 +21,7 @@ __device__ __forceinline__ float rank_sigmoid(float x) {
 int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                     float* scores_out, int spec, const void* planes_ws, hipStream_t st);
+                     float* scores_out, int spec, const void* planes_ws, hipStream_t st, int vs_loss = 0);
 
 // ge_rank_f16.hip: the split-precision sweep (embedding_dim % 8 == 0 in 56 ... 288, max_norm <= 8), ranks or scores.
 // planes_ws: the candidates' fp16 planes + entity -> position map (rank_planes_launch into rank_planes_bytes bytes, 256-byte

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
-    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
+    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* true_loss,
     float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags,
     const int32_t* __restrict__ pos_of, const _Float16* __restrict__ planes) {
   constexpr bool SCORES = MODE == 1;
@@ -320,7 +320,9 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
         lds.extra[qrow] = 0;
         const int32_t tid = (MODE != 2 && r < B) ? true_id[r] : -1;
         lds.tI[qrow] = tid;
-        lds.tP[qrow] = (tid >= 0 && tid < N) ? pos_of[tid] : -1;
+        // (sweep_flags & 2, ranking against GIVEN losses: the "true candidate" pass still runs -- the loop below has one
+        // copy of the MFMA code -- on candidate 0's planes, and its result is replaced by the given loss)
+        lds.tP[qrow] = (sweep_flags & 2) ? (r < B ? 0 : -1) : (tid >= 0 && tid < N) ? pos_of[tid] : -1;
       }
       if (t < 4) lds.next[t] = 2;                                // (blocks 0 and 1 of a slice go to its two waves up front)
     }
@@ -400,13 +402,24 @@ __global__ __launch_bounds__(kBlk) void rank_f16_kernel(
           // Near saturation (g < 1e-5, |score| > 11.5) no finite bracket gives that margin: it is infinite there and
           // every candidate of the row takes the exact comparison.  A true entity that is not among the candidates has
           // no rank: NaN bracket, NaN loss, no bit is ever set.
-          const float xp = lds.tP[t] < 0 ? __builtin_nanf("") : lds.eT[t], sa = lds.sA[t];
-          const float xs = xp * sa, e = rank_sigmoid(xs), gs = e * (1.0f - e);
-          const float wx = gs < 1e-5f ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
+          float xp = lds.tP[t] < 0 ? __builtin_nanf("") : lds.eT[t];
+          const float sa = lds.sA[t];
+          float xs = xp * sa, e = rank_sigmoid(xs);
+          if ((sweep_flags & 2) && lds.tP[t] >= 0) {
+            // ranking against a GIVEN loss (ge_rank_1vK_vs_loss: the candidate it belongs to need not be in this list):
+            // the bracket is centred on its logit -- rounded, but by orders of magnitude less than the bracket's
+            // 1e-6 in loss units -- and the exact comparison inside the bracket is against the given value itself
+            e = true_loss[m0 + t];
+            const float ec = fminf(fmaxf(e, 1e-30f), 0.99999994f);
+            xs = (e == e) ? logf(ec / (1.0f - ec)) : e;
+            xp = xs / sa;
+          }
+          const float gs = e * (1.0f - e);
+          const float wx = !(gs >= 1e-5f) ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
           const float wq = wx / sa;
           lds.lohi[t] = make_float2(xp - wq, xp + wq);
           lds.eT[t] = e;
-          if (true_loss && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
+          if (true_loss && !(sweep_flags & 2) && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
         }
         __syncthreads();
         diag = false;

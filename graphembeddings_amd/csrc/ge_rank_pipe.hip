@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
     const float* __restrict__ table, int64_t N, int d, const int32_t* __restrict__ hr, int64_t B,
     const int32_t* __restrict__ true_id, const int32_t* __restrict__ cand, int64_t K, float max_norm,
     int cand_is_head, const int32_t* __restrict__ known_off, const uint16_t* __restrict__ known_rc,
-    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* __restrict__ true_loss,
+    int32_t* __restrict__ raw_cnt, int32_t* __restrict__ skip_cnt, float* true_loss,
     float* __restrict__ scores_out, int n_ct, int64_t n_tiles, int spec, int sweep_flags) {
   constexpr bool SCORES = MODE == 1;
   using C = Cfg<CW>;
@@ -377,13 +377,23 @@ __global__ __launch_bounds__(kBlock) void rank_pipe_kernel(
         // (< 1.5e-7 each side) can move: outside the bracket the order of the losses is the order of the raw scores.
         // Near saturation (g < 1e-5, |score| > 11.5) no finite bracket gives that margin: it is infinite there and
         // every candidate of the row takes the exact comparison.
-        const float xp = lds.eT[t], sa = lds.sA[t];
-        const float xs = xp * sa, e = rank_sigmoid(xs), gs = e * (1.0f - e);
-        const float wx = gs < 1e-5f ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
+        float xp = lds.eT[t];
+        const float sa = lds.sA[t];
+        float xs = xp * sa, e = rank_sigmoid(xs);
+        if ((sweep_flags & 2) && m0 + t < B) {
+          // ranking against a GIVEN loss (ge_rank_1vK_vs_loss; the tile above ran on whatever row the tie-break id names):
+          // bracket centred on the loss's logit, exact comparisons against the given value (see ge_rank_f16.hip)
+          e = true_loss[m0 + t];
+          const float ec = fminf(fmaxf(e, 1e-30f), 0.99999994f);
+          xs = (e == e) ? logf(ec / (1.0f - ec)) : e;
+          xp = xs / sa;
+        }
+        const float gs = e * (1.0f - e);
+        const float wx = !(gs >= 1e-5f) ? __builtin_inff() : 1e-6f / gs + 4e-7f * fabsf(xs);
         const float wq = wx / sa;
         lds.lohi[t] = make_float2(xp - wq, xp + wq);
         lds.eT[t] = e;
-        if (true_loss && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
+        if (true_loss && !(sweep_flags & 2) && ct0 == 0 && m0 + t < B) true_loss[m0 + t] = e;
       }
       __syncthreads();
     }
@@ -547,9 +557,9 @@ int sweep_pipe_launch(const float*, int64_t, int32_t, const int32_t*, int64_t, c
 int rank_pipe_launch(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* true_id,
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
-                     float* scores_out, int spec, const void* planes_ws, hipStream_t st) {
+                     float* scores_out, int spec, const void* planes_ws, hipStream_t st, int vs_loss) {
   return sweep_pipe_launch(table, N, d, hr, B, true_id, cand, K, max_norm, cand_is_head, known_off, known_rc, raw_cnt,
-                           skip_cnt, true_loss, scores_out, spec, 0, 0, planes_ws, st);
+                           skip_cnt, true_loss, scores_out, spec, 0, vs_loss ? 2 : 0, planes_ws, st);
 }
 
 // ge_complex_score_1vK on the same pipeline: out [B,K] = score (sigmoid when apply_sigmoid)

@@ -76,7 +76,8 @@ class KnownIndex:
 @torch.no_grad()
 def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, candidates: np.ndarray,
                           known_triples: np.ndarray = None, side: str = "tail", batch: int = None,
-                          max_norm: float = 1.0, fused: bool = None, model: str = "complex", planes=None):
+                          max_norm: float = 1.0, fused: bool = None, model: str = "complex", planes=None,
+                          infer_threshold: float = None, return_confident: bool = False):
     """Raw and filtered rank of every test triple's true entity among `candidates`, with the
     semantics of holE.py:446-469.  side="tail": candidates replace the tail; "head": the head.
     known_triples: an [n,3] array, or a KnownIndex built for this side (evaluate_fb15k_style keeps the two it builds).
@@ -88,7 +89,11 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
     where HolE is the ComplEx-shaped form the sweep computes) or "hole_spectral" (table already there).  HolE
     needs the fused sweep.
     planes: H.RankPlanes of (embeddings, candidates) shared between calls (tails then heads: evaluate_fb15k_style); built
-    here otherwise -- once for all the batches of the call."""
+    here otherwise -- once for all the batches of the call.
+    infer_threshold: the reference's gate (holE.py:436-438, flag holE.py:616): a sweep is `is_confident` when the lowest
+    loss among its candidates is below the threshold, and ONLY confident sweeps record their positions (holE.py:464-466)
+    -- the returned arrays then hold the confident rows' ranks only (return_confident=True adds the bool mask over all
+    test rows).  None: every row is recorded (the reference with a threshold above every loss)."""
     assert side in ("tail", "head")
     if model not in ("complex", "hole", "hole_spectral"):
         raise ValueError(f"unknown model {model!r}")
@@ -114,12 +119,14 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
         # test rows per call: the stored-scores path holds a [batch, K] fp32 matrix; the fused sweep holds nothing
         # per row, and longer calls amortise its per-row-block set-up (the whole FB15k test set is one call)
         batch = 1 << 17 if fused else 16384
-    raw_all, fil_all = [], []
+    raw_all, fil_all, conf_all = [], [], []
     fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
     if fused and planes is None:
         planes = H.RankPlanes(embeddings, cand, max_norm=max_norm, model=model)
     if planes is not None:
-        if planes.cand.numel() != cand.numel():
+        # the planes' own id tensor is handed to the kernel: it has to BE this candidate list (pos_of and the known cells
+        # below are built from the caller's), not merely as long
+        if planes.cand.numel() != cand.numel() or not bool(torch.equal(planes.cand.to(dev), cand)):
             raise ValueError("`planes` were built for another candidate list")
         cand = planes.cand
     for s in range(0, len(test), batch):
@@ -151,15 +158,29 @@ def link_prediction_ranks(embeddings: torch.Tensor, test_triples: np.ndarray, ca
             if rows_t.numel():
                 skipped.index_add_(0, rows_t, before[rows_t, cols_t].to(torch.int64))
             fil = raw - skipped
+        if infer_threshold is not None:
+            # is_confident: the sweep's lowest loss is below the threshold <=> some candidate ranks before a loss equal to it
+            if fused:
+                conf = H.confident_rows(embeddings, hr, cand, infer_threshold, cand_is_head=(side == "head"), max_norm=max_norm,
+                                        model=model, planes=planes)
+            else:
+                conf = scores.min(dim=1).values < infer_threshold
+            raw, fil = raw[conf], fil[conf]
+            conf_all.append(conf.cpu().numpy())
         raw_all.append(raw.cpu().numpy())
         fil_all.append(fil.cpu().numpy())
-    return np.concatenate(raw_all), np.concatenate(fil_all)
+    out = (np.concatenate(raw_all), np.concatenate(fil_all))
+    if return_confident:
+        out += (np.concatenate(conf_all) if conf_all else np.ones(len(test), dtype=bool),)
+    return out
 
 
 def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True, batch: int = None,
-                         verbose: bool = True, model: str = "complex") -> dict:
+                         verbose: bool = True, model: str = "complex", infer_threshold: float = None) -> dict:
     """Filtered link prediction over all entities (rows >= relation_count) for
-    data.test_array, filtering train+valid triples as the reference does (holE.py:413-422)."""
+    data.test_array, filtering train+valid triples as the reference does (holE.py:413-422).
+    infer_threshold: the reference's is_confident gate (holE.py:436-438); the summary then covers the confident sweeps
+    only and carries their number (`recorded` of `sweeps`)."""
     R, N = data.relation_count, data.entity_count
     cand = np.arange(R, N, dtype=np.int32)
     parts = [a for a in (data.triples, data.validation_triples) if a is not None]
@@ -174,16 +195,28 @@ def evaluate_fb15k_style(embeddings: torch.Tensor, data, both_sides: bool = True
     # evaluations of a training run
     cache = data.__dict__.setdefault("_known_index_cache", {}) if hasattr(data, "__dict__") else {}
     def known_index(side):
-        key = (side, str(embeddings.device), N, 0 if known is None else len(known))
+        # keyed on the IDENTITY of the split arrays (kept alive by `data`) as well as their length: a data object whose
+        # train / valid triples are replaced by others of the same count must not reuse the old filter
+        key = (side, str(embeddings.device), N, 0 if known is None else len(known), tuple(id(a) for a in parts))
         if key not in cache:
             cache[key] = KnownIndex(known, N, side, embeddings.device)
         return cache[key]
-    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known_index("tail"), "tail", batch, model=model, planes=planes)
+    raw_t, fil_t = link_prediction_ranks(embeddings, data.test_array, cand, known_index("tail"), "tail", batch, model=model,
+                                         planes=planes, infer_threshold=infer_threshold)
     raw, fil = [raw_t], [fil_t]
     if both_sides:
-        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known_index("head"), "head", batch, model=model, planes=planes)
+        raw_h, fil_h = link_prediction_ranks(embeddings, data.test_array, cand, known_index("head"), "head", batch, model=model,
+                                             planes=planes, infer_threshold=infer_threshold)
         raw.append(raw_h); fil.append(fil_h)
-    out = mrr_and_hits(np.concatenate(raw), np.concatenate(fil))
+    raw, fil = np.concatenate(raw), np.concatenate(fil)
+    sweeps = len(data.test_array) * (2 if both_sides else 1)
+    if raw.size == 0:      # no sweep was confident: the reference would take the mean of nothing (holE.py:477)
+        out = {k: float("nan") for k in ("raw_mrr", "mean_raw_pos", "filtered_mrr", "mean_filtered_pos", "hits1", "hits3", "hits10")}
+    else:
+        out = mrr_and_hits(raw, fil)
+    out["recorded"], out["sweeps"] = int(raw.size), int(sweeps)
+    if verbose and infer_threshold is not None:
+        print(f"is_confident (lowest loss < {infer_threshold}): {raw.size} of {sweeps} sweeps recorded")
     if verbose:
         print("raw MRR {raw_mrr:.6f} (mean rank {mean_raw_pos:.1f}); filtered MRR {filtered_mrr:.6f} "
               "(mean rank {mean_filtered_pos:.1f}); hits@1/3/10 {hits1:.2f} / {hits3:.2f} / {hits10:.2f} %".format(**out))

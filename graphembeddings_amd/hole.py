@@ -398,6 +398,59 @@ def rank_candidates(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, 
     return out
 
 
+def rank_candidates_vs_loss(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, ref_ids: torch.Tensor,
+                            ref_losses: torch.Tensor, candidates: torch.Tensor, *, known_off: Optional[torch.Tensor] = None,
+                            known_rc: Optional[torch.Tensor] = None, cand_is_head: bool = False, max_norm: float = 1.0,
+                            model: str = "complex", planes: Optional[RankPlanes] = None):
+    """The sweep of rank_candidates against GIVEN losses (ge_rank_1vK_vs_loss): per row how many of `candidates` pop from
+    the reference's heap (holE.py:427-472: ascending loss, ties by id) before a triple of loss ref_losses[i] and id
+    ref_ids[i] -- which need not be among them -- and how many of those are known-true.  What a rank of a row-sharded
+    evaluation computes over its own candidates (the counts add across ranks), and what the reference's is_confident
+    gate (holE.py:436-438) reduces to: min_loss < threshold  <=>  n_before(threshold, id = INT32_MIN) > 0."""
+    if model not in ("complex", "hole_spectral"):
+        raise ValueError("rank_candidates_vs_loss: model must be 'complex' or 'hole_spectral'")
+    emb = _table(embeddings)
+    for name, t in (("fixed_and_relation", fixed_and_relation), ("ref_ids", ref_ids), ("ref_losses", ref_losses),
+                    ("candidates", candidates)):
+        _need_cuda(t, name)
+    hr = fixed_and_relation.to(torch.int32).contiguous()
+    rid = ref_ids.to(torch.int32).contiguous().view(-1)
+    rl = ref_losses.to(torch.float32).contiguous().view(-1)
+    cand = candidates.to(torch.int32).contiguous().view(-1)
+    B, K = hr.shape[0], cand.numel()
+    if hr.dim() != 2 or hr.shape[1] != 2 or rid.numel() != B or rl.numel() != B:
+        raise ValueError("fixed_and_relation must be [B,2] (entity, relation), ref_ids and ref_losses [B]")
+    if (known_off is None) != (known_rc is None):
+        raise ValueError("known_off and known_rc come together")
+    pl = None
+    if planes is not None and planes.buffer is not None:
+        same = planes.key == (emb.data_ptr(), emb.shape[0], emb.shape[1], planes.cand.data_ptr(), K, float(max_norm), model)
+        if same and cand.data_ptr() != planes.cand.data_ptr():
+            same = bool(torch.equal(planes.cand, cand))
+        if not same:
+            raise ValueError("rank_candidates_vs_loss: `planes` were built for another table / candidate list / max_norm / model")
+        cand, pl = planes.cand, planes.buffer.data_ptr()
+    n_before = torch.empty(B, dtype=torch.int32, device=emb.device)
+    n_known = torch.empty(B, dtype=torch.int32, device=emb.device)
+    _lib.call("ge_rank_1vK_vs_loss", emb.data_ptr(), emb.shape[0], emb.shape[1], hr.data_ptr(), B, rid.data_ptr(),
+              rl.data_ptr(), cand.data_ptr(), K, max_norm, _MODELS[model], int(cand_is_head),
+              known_off.data_ptr() if known_off is not None else None,
+              known_rc.data_ptr() if known_rc is not None else None, n_before.data_ptr(), n_known.data_ptr(), pl, _stream())
+    return n_before, n_known
+
+
+def confident_rows(embeddings: torch.Tensor, fixed_and_relation: torch.Tensor, candidates: torch.Tensor, infer_threshold: float,
+                   **kw) -> torch.Tensor:
+    """is_confident of holE.py:436-438 for every row of a sweep: min over the candidates of the loss < infer_threshold,
+    as a bool tensor [B] -- one more sweep, counting the candidates below the threshold (no [B,K] matrix)."""
+    B = fixed_and_relation.shape[0]
+    dev = embeddings.device
+    thr = torch.full((B,), float(infer_threshold), dtype=torch.float32, device=dev)
+    lowest = torch.full((B,), -2 ** 31, dtype=torch.int32, device=dev)        # no candidate id is smaller: strict "<" only
+    n_before, _ = rank_candidates_vs_loss(embeddings, fixed_and_relation, lowest, thr, candidates, **kw)
+    return n_before > 0
+
+
 class ValidationPocket:
     """The validation ticks of the training loop (holE.py:299-304, 351-360) without a host round trip per tick
     (ge_validation_tick): each tick draws a validation batch on the device, corrupts it, takes the mean hinge into

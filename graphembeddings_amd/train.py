@@ -220,7 +220,8 @@ def infer_triples(FLAGS, log=print) -> dict:
     data = D.init_inference_data(FLAGS.data_dir, min_mentions=None)
     emb, _ = load_checkpoint(FLAGS.output_dir)
     # --model hole: the checkpoint holds the real-valued table; ranks use the HolE score (README.md:42), not ComplEx
-    return E.evaluate_fb15k_style(emb, data, both_sides=True, model=FLAGS.model)
+    # positions are recorded for confident sweeps only: lowest loss < --infer_threshold (holE.py:436-438, 464-466, 616)
+    return E.evaluate_fb15k_style(emb, data, both_sides=True, model=FLAGS.model, infer_threshold=FLAGS.infer_threshold)
 
 
 def main(argv=None):

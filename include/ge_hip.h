@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE_VERSION 310 /* 0.3.1: + ge_rank_planes / ge_rank_1vK_planes (candidate planes built once), ge_known_cells */
+#define GE_VERSION 320 /* 0.3.2: + ge_rank_1vK_vs_loss (ranks against given losses: sharded candidate lists, the is_confident gate) */
 
 /* argument errors (negative, -errno style) */
 #define GE_EINVAL (-22)  /* bad dimension / null pointer / misaligned buffer */
@@ -244,6 +244,20 @@ int ge_rank_1vK_planes(const float* table, int64_t N, int32_t d, const int32_t* 
                        const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head, const int32_t* known_off,
                        const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before, float* true_loss,
                        float* scores_out, const void* planes, void* stream);
+
+/* The same sweep against GIVEN losses: n_before[i] = #{ j : E_ij < ref_loss[i], or E_ij == ref_loss[i] and cand[j] <
+ * ref_id[i] }, n_known_before[i] = how many of those are listed in the known cells -- i.e. the position the reference's
+ * heap (holE.py:427-472) would give a triple of loss ref_loss[i] and tail id ref_id[i] among THESE candidates, whether or
+ * not it is one of them.  Two uses: (1) a candidate list sharded over several devices -- each sweeps its own candidates
+ * against the true triple's loss (computed once, by whoever holds the true candidate: ge_rank_1vK_planes' true_loss) and
+ * the counts ADD across shards (exactly: equal table rows give bit-equal losses on every device); (2) the reference's
+ * `is_confident = min_loss < infer_threshold` gate (holE.py:436-438): min_loss < t  <=>  n_before(ref_loss = t, ref_id
+ * = INT32_MIN) > 0.  ref_id need not be a table row.  planes: as ge_rank_1vK_planes (NULL: built per call).
+ * embedding_dim % 8 == 0 up to ge_rank_max_dim() (above 232 only with the planes' conditions), else GE_ENOTSUP. */
+int ge_rank_1vK_vs_loss(const float* table, int64_t N, int32_t d, const int32_t* hr, int64_t B, const int32_t* ref_id,
+                        const float* ref_loss, const int32_t* cand, int64_t K, float max_norm, int model, int cand_is_head,
+                        const int32_t* known_off, const uint16_t* known_rc, int32_t* n_before, int32_t* n_known_before,
+                        const void* planes, void* stream);
 
 /* --- the known_off / known_rc lists of ge_rank_1vK from a sorted index of the known-true triples (the filter of
  * holE.py:454-463, built by the reference as a dict of sets, holE.py:413-422).  known_key [M] ascending = fixed entity *

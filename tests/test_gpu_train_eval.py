@@ -500,3 +500,81 @@ def test_fb15k_mrr_parity_gpu_path_vs_cpu_port():
     assert cross["differences_explained_by_candidates_within_5e-7_of_the_true_loss"] == n
     assert res["filtered_mrr_abs_diff"] < 1e-3
     assert res["metrics_gpu_path"]["filtered_mrr"] > 1.5 * res["metrics_untrained"]["filtered_mrr"]     # it learned
+
+
+@pytest.mark.parametrize("d,model", [(200, "complex"), (64, "complex"), (104, "hole_spectral"), (40, "complex"), (48, "complex")])
+def test_ranks_against_given_losses_add_over_candidate_shards(d, model):
+    """ge_rank_1vK_vs_loss: (1) ranking every row against ITS OWN true loss and id gives ge_rank_1vK_planes' counts;
+    (2) the candidate list cut into 3 ragged shards (the true candidate is in one of them, or -- rows 0..9 -- in none):
+    the shards' counts against the true loss ADD to the one-list counts, raw and known, bit for bit: what a row-sharded
+    evaluation all-reduces (holE.py:427-472 positions are sums over disjoint candidate sets)."""
+    from graphembeddings_amd import evaluate as E
+    from graphembeddings_amd import hole as H
+    rng = np.random.default_rng(d)
+    R, N, B = 4, 700, 300
+    table = (rng.standard_normal((N, d)) * 0.2).astype(np.float32)
+    table[50] = table[51]; table[60] = table[61]            # exact ties: the id decides
+    emb = torch.as_tensor(table).cuda()
+    if model == "hole_spectral":
+        emb = H.hole_to_spectral(emb)
+    cand = np.arange(R, N).astype(np.int32)
+    test = np.stack([rng.integers(R, N, B), rng.integers(R, N, B), rng.integers(0, R, B)], 1)
+    test[:4, 1] = [50, 51, 60, 61]
+    known = np.stack([np.repeat(test[:, 0], 5), rng.integers(R, N, 5 * B), np.repeat(test[:, 2], 5)], 1)
+    known = known[~(known[:, None, :] == test[None, :, :]).all(-1).any(1)]
+    for side in ("tail", "head"):
+        fixed_col, true_col = (0, 1) if side == "tail" else (1, 0)
+        kn = known if side == "tail" else known[:, [1, 0, 2]]
+        kn = kn[~(kn[:, None, :] == test[None, :, :]).all(-1).any(1)]
+        hr = torch.as_tensor(np.stack([test[:, fixed_col], test[:, 2]], 1).astype(np.int32)).cuda()
+        tid = torch.as_tensor(test[:, true_col].astype(np.int32)).cuda()
+        index = E.KnownIndex(kn, N, side, emb.device)
+
+        def cells(c):
+            pos_of = torch.full((N,), -1, dtype=torch.int64, device="cuda")
+            pos_of[torch.as_tensor(c.astype(np.int64)).cuda()] = torch.arange(len(c), device="cuda")
+            return index.cells(hr[:, 0].long(), hr[:, 1].long(), pos_of, len(c))
+        dc = torch.as_tensor(cand).cuda()
+        off, rc = cells(cand)
+        nb, nk, tl = H.rank_candidates(emb, hr, tid, dc, known_off=off, known_rc=rc, cand_is_head=(side == "head"),
+                                       return_true_loss=True, model=model)
+        nb2, nk2 = H.rank_candidates_vs_loss(emb, hr, tid, tl, dc, known_off=off, known_rc=rc, cand_is_head=(side == "head"), model=model)
+        assert torch.equal(nb, nb2) and torch.equal(nk, nk2), side
+        perm = rng.permutation(cand)
+        cuts = [0, 231, 500, len(cand)]
+        sb = torch.zeros_like(nb); sk = torch.zeros_like(nk)
+        for a, b in zip(cuts, cuts[1:]):
+            c = np.sort(perm[a:b])
+            o2, r2 = cells(c)
+            x, y = H.rank_candidates_vs_loss(emb, hr, tid, tl, torch.as_tensor(c).cuda(), known_off=o2, known_rc=r2,
+                                             cand_is_head=(side == "head"), model=model)
+            sb += x; sk += y
+        assert torch.equal(sb, nb) and torch.equal(sk, nk), side
+
+
+@pytest.mark.parametrize("d,fused", [(200, True), (64, True), (40, True), (50, False)])
+def test_is_confident_gate_equals_the_reference_heap(d, fused):
+    """--infer_threshold (holE.py:436-438, 464-466): only sweeps whose lowest loss is below the threshold record their
+    positions.  link_prediction_ranks(infer_threshold=...) against the oracle's restatement fed with the sweep's own losses;
+    thresholds chosen between the rows' minima (so some rows are confident and some are not) and one ON a row's minimum
+    (strict <)."""
+    from graphembeddings_amd import evaluate as E
+    rng = np.random.default_rng(7)
+    R, N, B = 3, 260, 90
+    table = (rng.standard_normal((N, d)) * 0.45).astype(np.float32)
+    emb = torch.as_tensor(table).cuda()
+    test = np.stack([rng.integers(R, N, B), rng.integers(R, N, B), rng.integers(0, R, B)], 1)
+    cand = np.arange(R, N)
+    scores = _all_scores(emb, test, cand, "tail", fused)
+    mins = np.sort(scores.min(1))
+    for thr in (float((mins[B // 3] + mins[B // 3 + 1]) / 2), float(mins[B // 2]), 0.0, 1.5):
+        raw, fil, conf = E.link_prediction_ranks(emb, test, cand, None, side="tail", fused=fused, infer_threshold=thr, return_confident=True)
+        rp, fp, exp_conf = [], [], []
+        for i, (h, t, r) in enumerate(test):
+            triples = np.stack([np.full(len(cand), h), cand, np.full(len(cand), r)], 1)
+            n0 = len(rp)
+            O.eval_link_prediction(scores[i], triples, O.triple_dict([]), O.triple_dict([[h, t, r]]), rp, fp, infer_threshold=thr)
+            exp_conf.append(len(rp) > n0)
+        assert list(conf) == exp_conf, thr
+        assert list(raw) == rp and list(fil) == fp, thr
+        assert 0 < sum(exp_conf) < B or thr in (0.0, 1.5)
