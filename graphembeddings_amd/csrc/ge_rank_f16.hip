@@ -658,13 +658,17 @@ int f16_launch_kkb(const float* table, int64_t N, int32_t d, const int32_t* hr, 
 int64_t rank_planes_bytes(int64_t N, int32_t d, int64_t K) {
   if (d % 8 != 0 || d < 56 || d > 288 || N <= 0 || K <= 0) return 0;
   const int64_t kkb = (d + 15) / 16;
-  return pos_bytes(N) + planes_slices(K) * kkb * 2 * kOpHalves * (int64_t)sizeof(_Float16);
+  const int64_t plane_bytes = planes_slices(K) * kkb * 2 * kOpHalves * (int64_t)sizeof(_Float16);
+  // the sweep addresses the planes with 32-bit byte offsets (about 5.1 M candidates at d = 200): beyond that there is no
+  // split-precision sweep -- said HERE, so that nobody allocates and fills 4 GiB of planes the sweep then refuses
+  if (plane_bytes >= ((int64_t)1 << 32)) return 0;
+  return pos_bytes(N) + plane_bytes;
 }
 
 // planes_ws (rank_planes_bytes, 256-byte aligned) <- the entity -> position map, then the candidates' fp16 planes
 int rank_planes_launch(const float* table, int64_t N, int32_t d, const int32_t* cand, int64_t K, float max_norm, int spec,
                        void* planes_ws, hipStream_t st) {
-  if (!f16_dim_ok(d, max_norm)) return GE_ENOTSUP;
+  if (!f16_dim_ok(d, max_norm) || (K > 0 && N > 0 && rank_planes_bytes(N, d, K) == 0)) return GE_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(planes_ws) % 256 != 0 || reinterpret_cast<uintptr_t>(table) % 16 != 0) return GE_EINVAL;
   if (K <= 0 || N <= 0) return 0;
   int32_t* pos_of = reinterpret_cast<int32_t*>(planes_ws);
@@ -690,7 +694,7 @@ int sweep_f16_launch(const float* table, int64_t N, int32_t d, const int32_t* hr
                      const int32_t* cand, int64_t K, float max_norm, int cand_is_head, const int32_t* known_off,
                      const uint16_t* known_rc, int32_t* raw_cnt, int32_t* skip_cnt, float* true_loss,
                      float* scores_out, int spec, int scores_only, int sweep_flags, const void* planes_ws, hipStream_t st) {
-  if (!f16_dim_ok(d, max_norm)) return GE_ENOTSUP;
+  if (!f16_dim_ok(d, max_norm) || rank_planes_bytes(N, d, K) == 0) return GE_ENOTSUP;   // (incl. planes beyond 32-bit offsets)
   static_assert(h_lds_bytes<18>() <= 160 * 1024, "LDS of the largest instantiation");
   void* own = nullptr;
   if (!planes_ws) {

@@ -106,24 +106,27 @@ __global__ __launch_bounds__(kBlock) void bernoulli_corrupt_kernel(
     const int32_t* ent_arr = tail_side ? bh_ent : bt_ent;
     const int64_t key = (int64_t)(tail_side ? t[0] : t[1]) * n_rel + r;
     const int col = tail_side ? 1 : 0;
-    const int64_t ll = lower_bound64(key_arr, n_known, key);
-    const int64_t rr = upper_bound64(key_arr, n_known, key) - 1;
-    const int64_t cnt = rr >= ll ? rr - ll + 1 : 0;
+    // the known completions of (fixed entity, relation): a sorted run [first, last] of ent_arr
+    const int64_t first = lower_bound64(key_arr, n_known, key);
+    const int64_t last = upper_bound64(key_arr, n_known, key) - 1;
+    const int64_t cnt = last >= first ? last - first + 1 : 0;
     const int64_t free_n = (int64_t)n_ent - cnt;
     int32_t repl = -1;
     if (free_n > 0) {
-      const int64_t tmp = (int64_t)(((uint64_t)w_pick * (uint64_t)free_n) >> 32);
+      // the draw-th entity that is NOT a known completion (init.cpp:159-190: skip the known ones by bisection on
+      // "free entities below the p-th known one" = ent[p] - ent_lo - (p - first))
+      const int64_t draw = (int64_t)(((uint64_t)w_pick * (uint64_t)free_n) >> 32);
+      auto free_below = [&](int64_t p) { return (int64_t)ent_arr[p] - ent_lo - (p - first); };
       int64_t j;
-      if (cnt == 0) j = tmp;
-      else if (tmp < (int64_t)ent_arr[ll] - ent_lo) j = tmp;
-      else if (tmp > (int64_t)ent_arr[rr] - ent_lo - rr + ll - 1) j = tmp + rr - ll + 1;
+      if (cnt == 0 || draw < free_below(first)) j = draw;
+      else if (draw >= free_below(last)) j = draw + cnt;
       else {
-        int64_t lef = ll, rig = rr + 1;
-        while (lef + 1 < rig) {
-          const int64_t mid = (lef + rig) >> 1;
-          if ((int64_t)ent_arr[mid] - ent_lo - mid + ll - 1 < tmp) lef = mid; else rig = mid;
+        int64_t below = first, above = last + 1;        // free_below(below) <= draw < free_below(above)
+        while (below + 1 < above) {
+          const int64_t probe = (below + above) >> 1;
+          if (free_below(probe) <= draw) below = probe; else above = probe;
         }
-        j = tmp + lef - ll + 1;
+        j = draw + (below - first + 1);
       }
       repl = ent_lo + (int32_t)j;
     }

@@ -9,8 +9,11 @@
  * transE.py:95-112): C linkage, caller-owned caller-sized flat buffers, int32 ids.  Differences
  * that make it usable from a GPU training loop: every entry point returns an int status
  * (0 = ok, <0 = -errno style argument error, >0 = hipError_t), takes the hipStream_t it must
- * enqueue on (as void*), never synchronises, never allocates device memory, and keeps no global
- * state (the only state is inside the explicit ge_train_pipeline handle, see ge_train_steps).
+ * enqueue on (as void*), never synchronises, allocates no device memory of its own -- with ONE exception,
+ * stated where it applies: ge_rank_1vK / ge_complex_rank_1vK / ge_rank_1vK_vs_loss without a `planes` buffer and
+ * ge_complex_score_1vK on large sweeps build the candidates' fp16 planes in a stream-ordered allocation
+ * (hipMallocAsync / hipFreeAsync on `stream`, nothing outlives the call; pass ge_rank_planes' buffer to avoid it) --
+ * and keeps no global state (the only state is inside the explicit ge_train_pipeline handle, see ge_train_steps).
  *
  * All pointers except where noted are DEVICE pointers (e.g. torch.Tensor.data_ptr()).
  * `table` is the single shared entity+relation table of holE.py:263-264: row-major fp32 [N, d],

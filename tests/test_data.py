@@ -120,3 +120,42 @@ def test_binary_triple_cache(tmp_path):
     import os, time
     os.utime(tmp_path / "triples.txt", (time.time() + 5, time.time() + 5))
     assert D.init_data(p, cache=True).triples.tolist() == [[2, 4, 0]]
+
+
+def test_read_triples_cached_side_car_stale_cache_and_read_only_dir(tmp_path):
+    """data.read_triples_cached: the binary side-car is written on first use, served (memory-mapped)
+    afterwards, REBUILT when the TSV is newer or the side-car is not an int32 [T,3] array, and a directory that cannot be
+    written to costs nothing but the cache."""
+    import os
+    import time
+    from graphembeddings_amd import data as D
+    p = str(tmp_path / "triples.txt")
+    a = np.array([[5, 6, 0], [7, 8, 1], [9, 10, 0]], dtype=np.int64)
+    D.write_triples(p, a)
+    got = D.read_triples_cached(p)
+    assert np.array_equal(got, a) and os.path.exists(p + ".npy")
+    again = D.read_triples_cached(p)
+    assert isinstance(again, np.memmap) and again.dtype == np.int32 and np.array_equal(again, a)
+    # stale: the TSV changes after the side-car was written
+    b = np.array([[1, 2, 0], [3, 4, 1]], dtype=np.int64)
+    D.write_triples(p, b)
+    os.utime(p, (time.time() + 5, time.time() + 5))
+    assert np.array_equal(D.read_triples_cached(p), b)
+    os.utime(p + ".npy", (time.time() + 10, time.time() + 10))
+    assert np.array_equal(D.read_triples_cached(p), b)          # and the rebuilt side-car is the new content
+    # a side-car of the wrong shape / dtype is not trusted
+    np.save(p + ".npy", np.zeros((4, 2), dtype=np.float32))
+    os.utime(p + ".npy", (time.time() + 20, time.time() + 20))
+    assert np.array_equal(D.read_triples_cached(p), b)
+    # read-only directory (skipped when running as root, who may write anywhere)
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    q = str(ro / "triples.txt")
+    D.write_triples(q, a)
+    os.chmod(ro, 0o555)
+    try:
+        assert np.array_equal(D.read_triples_cached(q), a)
+        if os.geteuid() != 0:
+            assert not os.path.exists(q + ".npy")
+    finally:
+        os.chmod(ro, 0o755)
