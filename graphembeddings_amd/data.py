@@ -70,7 +70,7 @@ def read_triples_cached(path: str) -> np.ndarray:
         pass
     arr = read_triples(path)
     try:
-        tmp = cache + ".tmp.npy"
+        tmp = cache + f".tmp{os.getpid()}.npy"          # (several ranks may build the side-car at once: one file each, last rename wins)
         np.save(tmp, arr)
         os.replace(tmp, cache)
     except OSError:

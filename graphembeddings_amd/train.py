@@ -59,6 +59,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--max_steps', type=int, default=0, help='Stop after this many steps (0 = epoch limit only).')
     p.add_argument('--checkpoint_seconds', type=float, default=300.,
                    help='Also write the best table found so far this often inside an epoch (0 = once per epoch only).')
+    p.add_argument('--gpus', type=int, default=1,
+                   help='Ranks (one per GPU) the table is row-sharded over; > 1 without a launcher: this program starts them '
+                        '(graphembeddings_amd/launch.py).  --batch_size stays the GLOBAL batch.')
     return p
 
 
@@ -226,6 +229,26 @@ def infer_triples(FLAGS, log=print) -> dict:
 
 def main(argv=None):
     FLAGS, _unparsed = build_parser().parse_known_args(argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if FLAGS.gpus > 1 and 'WORLD_SIZE' not in os.environ and not FLAGS.save_embeddings:
+        # no launcher: this process (which has not touched the GPU) becomes the parent of --gpus ranks of itself
+        from . import launch
+        sys.exit(launch.spawn_ranks(FLAGS.gpus, list(sys.argv[1:] if argv is None else argv), module='graphembeddings_amd.train'))
+    if world > 1 and FLAGS.gpus != world:
+        raise SystemExit(f'--gpus {FLAGS.gpus} but the launcher started {world} ranks')
+    if world > 1 and not FLAGS.save_embeddings:
+        from . import sharded_train as ST
+        if FLAGS.infer:
+            ST.infer_sharded(FLAGS)
+        else:
+            training_data = D.init_data(FLAGS.data_dir, cache=True)
+            if int(os.environ.get('RANK', '0')) == 0:
+                print('Entities: ', training_data.entity_count - training_data.relation_count, 'Relations: ',
+                      training_data.relation_count, 'Triples: ', training_data.triple_count)
+            ST.run_training_sharded(training_data, FLAGS)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
     if FLAGS.save_embeddings:
         save_embeddings(FLAGS)
     elif FLAGS.infer:
