@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="N>1, opt-in: fetch the rows of step s+1 that no rank touches in step s on a communication stream while "
                          "step s computes (bitwise the serial schedule's result; not yet run on RCCL)")
+    ap.add_argument("--capacity", default=None,
+                    help="N>1, opt-in: equal-split all-to-alls with this many rows per peer and step ('auto': 1.25 x the first "
+                         "chunk's largest count) -- no split size is read back, the whole run is enqueued ahead of the device; "
+                         "bitwise the exact schedule's result (gloo tests); not yet run on RCCL")
     ap.add_argument("--peer-mapped", action="store_true",
                     help="N>1 EXPERIMENT: map the other ranks' shards by IPC and read their rows in place instead of the row "
                          "all-to-all (two cross-rank barriers per step); rehearsed on one device only, needs peer access on hardware")

@@ -161,6 +161,7 @@ class ChunkPlan:
     req_start: list = None
     owner: object = None           # backend-private owner-side plan (None at world size 1)
     pre: FetchSplit = None         # overlapped schedule only
+    static: "StaticSplit" = None   # equal-split schedule only (ShardedTrainer(capacity=...))
     ready: object = None           # event recorded on the side stream when the plan was built there
     unique_rows: int = 0
     remote_rows: int = 0
@@ -188,6 +189,21 @@ class FetchSplit:
     done: dict = None              # step -> event recorded behind it on the communication stream
 
 
+@dataclass
+class StaticSplit:
+    """The equal-split schedule (ShardedTrainer(capacity=C)): every all-to-all moves exactly C rows per peer and step, so
+    no split size -- nothing data dependent -- ever has to reach the host.  Requester side: where staged row u sits in the
+    padded receive buffer (stage_index) and where the padded send-back buffer takes its rows from (back_index; unused
+    slots read the one all-zero row behind the gradient sums); the only read-back is the overflow flag, copied to pinned
+    memory on the stream the plan was built on and looked at when the plan is adopted."""
+    C: int
+    stage_index: torch.Tensor      # int64 [S, G*C]: padded receive position of staged row u (u >= the step's count: 0)
+    back_index: torch.Tensor       # int64 [S, G*C]: staged row sent back in padded slot (p, j); G*C = the zero row
+    over_host: torch.Tensor        # pinned int32 [1]: 1 when some (step, owner) needs more than C rows
+    over_ready: object = None      # event behind the copy into over_host
+    used_rows: torch.Tensor = None  # int64 [1] on the device: rows really requested in the chunk (statistics, read lazily)
+
+
 def _segment_sums(flags: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
     """Sum of `flags` over consecutive segments whose lengths are `lengths` (any shape, row-major)."""
     c = torch.cat([torch.zeros(1, dtype=torch.int64, device=flags.device), torch.cumsum(flags.to(torch.int64), 0)])
@@ -206,7 +222,7 @@ class StepStats:
 class ShardedTrainer:
     def __init__(self, shard: torch.Tensor, n_rows: int, type_tables, *, margin=0.2, model="complex",
                  max_norm=1.0, seed=0, corrupt_mode=0, kernels=None, group=None, plan_group=None, peer_mapped=False,
-                 overlap=False):
+                 overlap=False, capacity=None, capacity_margin=1.25, control_group=None):
         """peer_mapped (EXPERIMENT, one node, world <= 8, HipKernels): every rank maps the other ranks' shards into
         its address space (CUDA IPC handles exchanged once) and the gradient kernel reads the other owners' rows IN
         PLACE over the fabric: no gather, no row all-to-all, no staging buffer.  What it costs instead: two
@@ -219,7 +235,19 @@ class ShardedTrainer:
         them -- are gathered and sent on a communication stream while step s computes; only the remainder is fetched
         in front of step s+1.  Same arithmetic, bitwise the same table as the serial schedule
         (tests/test_gpu_sharded.py); one more flag exchange and one more size read-back per chunk.  All collectives
-        stay on ONE communicator and are issued in the same host order on every rank."""
+        stay on ONE communicator and are issued in the same host order on every rank.
+
+        capacity (opt-in; "auto" or rows per peer and step): the EQUAL-SPLIT schedule.  The exact schedule sizes every
+        all-to-all from the plan's per-peer counts, which the host reads back once per chunk -- and on one communicator
+        that read-back waits behind the all-to-alls of the chunk that is training, so the device idles once per chunk
+        while the host catches up.  With a static capacity C every all-to-all moves C rows per peer (unused slots: id -1,
+        zero rows), nothing data dependent reaches the host and the whole run is enqueued ahead of the device; the same
+        rows meet in the same order, so tables and losses are BITWISE the exact schedule's.  "auto": the first chunk is
+        planned exactly and C = capacity_margin x its largest per-peer count (agreed across ranks, rounded up to 64).  A
+        chunk that needs more than C somewhere is re-planned exactly: the overflow flag is computed before any of the
+        plan's collectives, read from pinned memory (a wait for the PLAN's stream, never the training stream) and
+        agreed by a one-word all-reduce on `control_group` -- a CPU (gloo) group, created here when none is given, so
+        the agreement never queues on the GPU communicator.  Padded bytes are what `stats.bytes_sent` reports."""
         self.shard = shard
         self.N = int(n_rows)
         self.d = int(shard.shape[1])
@@ -255,6 +283,19 @@ class ShardedTrainer:
             self._map_peer_shards()
         self._side = torch.cuda.Stream(device=shard.device) if shard.is_cuda else None
         self._pending = None    # (positives, first global step, plan) built ahead for the next run_pipelined call
+        self.capacity = None                       # rows per peer and step of the equal-split schedule (None: exact splits)
+        self._capacity_auto = False
+        self.capacity_margin = float(capacity_margin)
+        self.control_group = control_group
+        self.replanned_chunks = 0                  # chunks that overflowed the capacity and ran on exact splits
+        if capacity is not None and self.world > 1 and not self.peer_mapped and not self.overlap:
+            if capacity == "auto":
+                self._capacity_auto = True
+            else:
+                self.capacity = int(capacity)
+            if self.control_group is None:
+                # the agreement on "did anyone overflow" runs on the CPU: it must not queue behind GPU collectives
+                self.control_group = dist.new_group(backend="gloo") if dist.get_backend(group) != "gloo" else group
 
     def _map_peer_shards(self):
         """Exchange CUDA IPC handles of the shards (torch's own reduction: hipIpcGetMemHandle / OpenMemHandle) and keep
@@ -284,7 +325,7 @@ class ShardedTrainer:
         return recv
 
     # -- exchange plans -----------------------------------------------------------------------
-    def plan_chunk(self, pos: torch.Tensor, neg: torch.Tensor) -> "ChunkPlan":
+    def plan_chunk(self, pos: torch.Tensor, neg: torch.Tensor, exact: bool = False) -> "ChunkPlan":
         """pos, neg: [S,B,3] int32 (this rank's positives / negatives for S consecutive steps).  One sort of each
         step's gradient slots by (own rows, then owner, row) -- the backend's plan_requester -- gives the work items
         and the staging order; the request lists are exchanged once for the whole chunk (all_to_all_single of the
@@ -295,6 +336,8 @@ class ShardedTrainer:
         S, B = int(pos.shape[0]), int(pos.shape[1])
         rp = self.k.plan_requester(pos, neg, self.N, G, self.rank)
         counts = rp.counts.to(torch.int64)                              # [S,G]; column `rank` = distinct own rows
+        if G > 1 and self.capacity is not None and not exact:
+            return self._plan_chunk_static(rp, counts, S, B)
         if G == 1:
             own = int(counts.sum())                                     # the one host read-back (statistics only)
             zeros = [[0]] * S
@@ -328,6 +371,62 @@ class ShardedTrainer:
         pre = self._split_fetch(pos, neg, ask, sc, rc, rc_dev, rg, rmap, req_all, n, n_req) if self.overlap else None
         return ChunkPlan(S=S, B=B, sc=sc.tolist(), rc=rc.tolist(), req=rp, req_all=req_all, req_start=req_start,
                          owner=owner, pre=pre, unique_rows=own + n, remote_rows=n)
+
+    def _plan_chunk_static(self, rp: RequesterPlan, counts: torch.Tensor, S: int, B: int) -> "ChunkPlan":
+        """The equal-split plan: no host read-back except the overflow flag (see StaticSplit).  Index arithmetic on the
+        device only, static shapes throughout."""
+        G, C, dev = self.world, int(self.capacity), counts.device
+        ask = counts.clone()
+        ask[:, self.rank] = 0                                            # [S,G] rows wanted from each owner
+        over = (ask > C).any().to(torch.int32).view(1)
+        over_host = torch.empty(1, dtype=torch.int32, pin_memory=True) if dev.type == "cuda" else torch.empty(1, dtype=torch.int32)
+        over_host.copy_(over, non_blocking=True)
+        over_ready = None
+        if dev.type == "cuda":
+            over_ready = torch.cuda.Event()
+            over_ready.record(torch.cuda.current_stream(dev))
+        ends = torch.cumsum(ask, 1)                                      # staging order: runs of owner 0, 1, ...
+        off = ends - ask
+        cap_r = int(rp.req_row.shape[1])
+        j = torch.arange(C, device=dev).view(1, 1, C)
+        u = (off.unsqueeze(2) + j).clamp_(max=cap_r - 1)                 # [S,G,C] staged row of padded slot (p, j)
+        valid = j < ask.unsqueeze(2)
+        ids = torch.where(valid, rp.req_row.gather(1, u.view(S, G * C)).view(S, G, C).to(torch.int32),
+                          torch.full((), -1, dtype=torch.int32, device=dev))
+        send_ids = ids.permute(1, 0, 2).contiguous()                     # block p -> peer p
+        recv_ids = torch.empty_like(send_ids)
+        dist.all_to_all_single(recv_ids, send_ids, group=self.plan_group)
+        req_all = recv_ids.permute(1, 0, 2).reshape(-1).contiguous()     # per step: peer-major, C slots per peer
+        req_start = [s * G * C for s in range(S + 1)]
+        owner = self.k.plan_owner(req_all, req_start, int(self.shard.shape[0]))
+        # staged row u of a step sits at padded position owner(u) * C + (u - first u of that owner)
+        uu = torch.arange(G * C, device=dev).view(1, -1).expand(S, -1).contiguous()
+        p_of = torch.searchsorted(ends.contiguous(), uu, right=True).clamp_(max=G - 1)
+        stage_index = (p_of * C + (uu - off.gather(1, p_of))).clamp_(0, G * C - 1)
+        stage_index = torch.where(uu < ends[:, -1:], stage_index, torch.zeros((), dtype=torch.int64, device=dev))
+        back_index = torch.where(valid, off.unsqueeze(2) + j, torch.full((), G * C, dtype=torch.int64, device=dev)).view(S, G * C)
+        st = StaticSplit(C=C, stage_index=stage_index, back_index=back_index.contiguous(), over_host=over_host,
+                         over_ready=over_ready, used_rows=ask.sum().view(1))
+        return ChunkPlan(S=S, B=B, sc=None, rc=None, req=rp, req_all=req_all, req_start=req_start, owner=owner, static=st,
+                         unique_rows=0, remote_rows=S * (G - 1) * C)     # (the block a rank "sends" to itself never leaves it)
+
+    def _overflowed(self, plan: "ChunkPlan") -> bool:
+        """Did ANY rank's equal-split plan of this chunk need more than the capacity?  The local flag comes from pinned
+        memory (a wait for the stream the plan was built on); the agreement is a CPU all-reduce."""
+        st = plan.static
+        if st.over_ready is not None:
+            st.over_ready.synchronize()
+        flag = torch.tensor([int(st.over_host.item())], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.control_group)
+        return bool(flag.item())
+
+    def _set_auto_capacity(self, plan: "ChunkPlan") -> None:
+        """capacity="auto": from the first, exactly planned chunk -- the largest per-peer count anywhere, times the margin."""
+        most = max([max(max(r) for r in plan.sc), max(max(r) for r in plan.rc), 1])
+        t = torch.tensor([most], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.control_group)
+        self.capacity = int(-(-int(t.item() * self.capacity_margin) // 64) * 64)
+        self._capacity_auto = False
 
     def _split_fetch(self, pos, neg, ask, sc, rc, rc_dev, rg, rmap, req_all, n, n_req) -> "FetchSplit":
         """Early / late split of every step's fetch (see FetchSplit).  Owner side: which requested rows of step s no
@@ -392,7 +491,7 @@ class ShardedTrainer:
         owners (all-to-all), added there."""
         staged = gsum = None
         if self.world > 1:
-            sc, rc = plan.sc[s], plan.rc[s]
+            sc, rc = (plan.sc[s], plan.rc[s]) if plan.sc is not None else (None, None)
             if self.peer_mapped:
                 self._rank_barrier()                                    # every owner has finished the previous step's updates
                 gsum = torch.zeros(int(sum(sc)), self.d, dtype=self.shard.dtype, device=self.shard.device)
@@ -411,6 +510,14 @@ class ShardedTrainer:
                 if done is not None:
                     torch.cuda.current_stream(self.shard.device).wait_event(done)
                 gsum = torch.zeros_like(staged)
+            elif plan.static is not None:                               # equal splits: C rows per peer, nothing from the host
+                st = plan.static
+                req = plan.req_all[plan.req_start[s]:plan.req_start[s + 1]]
+                rows_out = self.k.gather_rows(self.shard, req)          # [G*C, d]; unused slots (id -1): zero rows
+                recv = torch.empty_like(rows_out)
+                dist.all_to_all_single(recv, rows_out, group=self.group)
+                staged = recv.index_select(0, st.stage_index[s])        # into staging order (rows past the step's count: unused)
+                gsum = torch.zeros(staged.shape[0] + 1, self.d, dtype=self.shard.dtype, device=self.shard.device)   # + the zero row
             else:
                 req = plan.req_all[plan.req_start[s]:plan.req_start[s + 1]]
                 rows_out = self.k.gather_rows(self.shard, req)          # owners gather ...
@@ -420,7 +527,12 @@ class ShardedTrainer:
         if self.peer_mapped:
             self._rank_barrier()                                        # nobody still reads rows that are about to change
         self.k.apply(self.shard, plan.req, s, gsum)                     # own rows in place, staged rows -> gsum
-        if self.world > 1:
+        if self.world > 1 and plan.static is not None:
+            back = gsum.index_select(0, plan.static.back_index[s])      # padded slot (p, j) <- its staged row's sum, or zeros
+            recv_g = torch.empty_like(back)
+            dist.all_to_all_single(recv_g, back, group=self.group)
+            self.k.owner_apply(self.shard, plan.owner, s, recv_g)
+        elif self.world > 1:
             recv_g = self._a2a(gsum, sc, rc)                            # sums back to the owners
             self.k.owner_apply(self.shard, plan.owner, s, recv_g)
         self.global_step += 1
@@ -442,17 +554,21 @@ class ShardedTrainer:
         recorded before enqueuing any step)."""
         pos = pos.to(torch.int32).contiguous()
         if self._side is None:
-            plan = self.plan_chunk(pos, self.sample_negatives(pos, first_step).to(torch.int32))
+            neg = self.sample_negatives(pos, first_step).to(torch.int32)
+            plan = self.plan_chunk(pos, neg)
             plan.ready = None
+            plan.inputs = (pos, neg)
             return plan
         if inputs_ready is None:
             self._side.wait_stream(torch.cuda.current_stream(pos.device))
         else:
             self._side.wait_event(inputs_ready)
         with torch.cuda.stream(self._side):
-            plan = self.plan_chunk(pos, self.sample_negatives(pos, first_step).to(torch.int32))
+            neg = self.sample_negatives(pos, first_step).to(torch.int32)
+            plan = self.plan_chunk(pos, neg)
             plan.ready = torch.cuda.Event()
             plan.ready.record(self._side)
+        plan.inputs = (pos, neg)
         return plan
 
     def _adopt(self, plan: "ChunkPlan") -> None:
@@ -465,6 +581,8 @@ class ShardedTrainer:
         tensors = list(self.k.plan_tensors(plan.req, plan.owner)) if hasattr(self.k, "plan_tensors") else []
         if plan.req_all is not None:
             tensors.append(plan.req_all)
+        if plan.static is not None:
+            tensors += [plan.static.stage_index, plan.static.back_index]
         if plan.pre is not None:
             split = [plan.pre.idx_early, plan.pre.idx_late, plan.pre.req_early, plan.pre.req_late]
             tensors += split
@@ -475,6 +593,19 @@ class ShardedTrainer:
         for t in tensors:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(cur)
+
+    def _settle(self, plan: "ChunkPlan") -> "ChunkPlan":
+        """Equal-split bookkeeping once a plan is adopted: an auto capacity is fixed from the first (exact) chunk; an
+        equal-split plan that overflowed the capacity on ANY rank is replaced by the exact plan of the same chunk."""
+        if self._capacity_auto and plan.static is None and self.world > 1:
+            self._set_auto_capacity(plan)
+        if plan.static is not None and self._overflowed(plan):
+            pos, neg = plan.inputs
+            self.replanned_chunks += 1
+            exact = self.plan_chunk(pos, neg, exact=True)               # (on the current stream: the rare path)
+            exact.inputs, exact.ready = plan.inputs, None
+            return exact
+        return plan
 
     def run_pipelined(self, chunks, lr_fn, lookahead: torch.Tensor = None) -> torch.Tensor:
         """Train the chunks (a sequence of pos [S,B,3] tensors) back to back.  The steps of chunk c are
@@ -504,9 +635,11 @@ class ShardedTrainer:
         losses = []
         for c in range(len(chunks)):
             self._adopt(plan)
+            plan = self._settle(plan)
             losses += [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
             done = plan
             plan = self._plan_ahead(chunks[c + 1], self.global_step, ready) if c + 1 < len(chunks) else None
+            # (equal splits: remote_rows counts the PADDED slots -- what the links really carry)
             self.stats = StepStats(unique_rows=done.unique_rows // done.S, remote_rows=done.remote_rows // done.S,
                                    bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)),
                                    early_rows=(sum(sum(r) for r in done.pre.sc_e) // done.S) if done.pre is not None else 0)
@@ -520,6 +653,8 @@ class ShardedTrainer:
         if neg is None:
             neg = self.sample_negatives(pos)
         plan = self.plan_chunk(pos, neg.to(torch.int32))
+        plan.inputs = (pos, neg.to(torch.int32))
+        plan = self._settle(plan)
         losses = [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
         self.stats = StepStats(unique_rows=plan.unique_rows // plan.S, remote_rows=plan.remote_rows // plan.S,
                                bytes_sent=int(plan.remote_rows // plan.S * (2 * self.d * 4 + 4)))

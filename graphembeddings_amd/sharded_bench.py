@@ -74,7 +74,9 @@ def run(args, emit=True):
     # run on a multi-GPU node yet; on ONE communicator every rank enqueues in program order.
     plan_group = dist.new_group(backend=backend) if (world > 1 and getattr(args, "plan_group", False)) else None
     tr = S.ShardedTrainer(shard, N, tt, margin=0.2, model=args.model, seed=0, plan_group=plan_group,
-                          peer_mapped=bool(getattr(args, "peer_mapped", False)), overlap=bool(getattr(args, "overlap", False)))
+                          peer_mapped=bool(getattr(args, "peer_mapped", False)), overlap=bool(getattr(args, "overlap", False)),
+                          capacity=(None if getattr(args, "capacity", None) in (None, "") else
+                                    ("auto" if args.capacity == "auto" else int(args.capacity))))
     batch_count = args.triples // (B * world)
     decay_steps = 32.0 * batch_count
     ev = H.Events(2)
@@ -161,7 +163,9 @@ def run(args, emit=True):
                                    f"table row-sharded (id % N) over {world} GPU(s), triples partitioned by head owner, "
                                    + ("rows read in place from IPC-mapped peer shards, all-to-all of gradient sums"
                                       if tr.peer_mapped else "RCCL all-to-all of ids/rows/gradient sums"),
-                       "schedule": "overlapped early fetch" if tr.overlap else "serial",
+                       "schedule": ("overlapped early fetch" if tr.overlap else
+                                    f"equal splits, {tr.capacity} rows per peer and step ({tr.replanned_chunks} chunks re-planned exactly)"
+                                    if tr.capacity is not None else "serial, exact splits"),
                        "batch_per_gpu": B, "embedding_dim": d, "table_rows": N,
                        "table_mb_per_gpu": round(rows * d * 4 / 1e6, 1), "parallelism": f"row-shard x{world}",
                        "per_gpu_value": 2.0 * B * K / el, "unique_rows_per_step": stats.unique_rows,

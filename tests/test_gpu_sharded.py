@@ -238,3 +238,77 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
     assert line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "weak"
     assert np.isfinite(line["config"]["final_mean_hinge"])
+
+
+def _static_worker(rank, world, port, q):
+    import torch.distributed as dist
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            from graphembeddings_amd import hole as H
+            from graphembeddings_amd import sharded as S
+            torch.cuda.set_device(0)
+            rng = np.random.default_rng(3)
+            N, d, B, steps = 60000, 200, 2048, 6
+            # (uniform ids, every triple its own pseudo-relation row: no row collects more than 16 slots in a step, so no
+            # float atomics anywhere and the two schedules must give the same bits)
+            tri = np.stack([rng.integers(0, N, (steps, world * B)), rng.integers(0, N, (steps, world * B)),
+                            rng.integers(0, N, (steps, world * B))], 2).astype(np.int32)
+            table = (rng.standard_normal((N, d)) * 0.05).astype(np.float32)
+            tt = H.TypeTables.from_host(np.zeros(N, np.int32), np.array([0, N], np.int64), np.arange(N, dtype=np.int32), padded_size=0)
+            mine = torch.as_tensor(np.ascontiguousarray(tri[:, rank * B:(rank + 1) * B])).cuda()
+            chunks = [mine[0:2].contiguous(), mine[2:4].contiguous(), mine[4:6].contiguous()]
+            outs, caps = [], []
+            for cap in (None, "auto", 1024):
+                shard = torch.as_tensor(np.ascontiguousarray(table[rank::world])).cuda()
+                tr = S.ShardedTrainer(shard, N, tt, margin=0.2, seed=21, capacity=cap)
+                losses = tr.run_pipelined(chunks, lambda gs: 0.1)
+                outs.append((tr.gather_full_table(), losses))
+                caps.append((tr.capacity, tr.replanned_chunks, tr.stats.bytes_sent))
+            torch.cuda.synchronize()
+            same = all(bool(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])) for o in outs[1:])
+            if rank == 0:
+                q.put(("ok", same, caps))
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
+    except Exception:
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def test_equal_split_schedule_real_kernels_bitwise_the_exact_one():
+    """ShardedTrainer(capacity=...) at world 2 with the real kernels: C rows per peer in every all-to-all, the received
+    rows brought into staging order and the gradient sums into padded order by index on the device, nothing read back
+    but the overflow flag -- same bits as the exact schedule; a capacity the steps overflow (1024 < the ~1,800 rows a rank
+    asks of its peer) re-plans every chunk exactly and still gives those bits."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_static_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    deadline, msg = time.time() + 420, None
+    while time.time() < deadline:
+        if not q.empty():
+            msg = q.get()
+            break
+        if not any(p.is_alive() for p in procs):
+            break
+        time.sleep(0.2)
+    if msg is None and not q.empty():
+        msg = q.get()
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
+    assert msg[0] == "ok", f"rank {msg[1]} failed:\n{msg[2]}"
+    _, same, caps = msg
+    assert same
+    assert caps[0][0] is None and caps[1][0] % 64 == 0 and caps[1][1] == 0        # auto: fixed after chunk 0, never overflowed
+    assert caps[2] [1] == 3                                                        # 1024 rows per peer: every chunk re-planned
+    assert caps[1][2] == 1 * caps[1][0] * (2 * 200 * 4 + 4)                        # the padded bytes (to the one peer) are what is reported

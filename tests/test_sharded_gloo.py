@@ -81,7 +81,9 @@ class OracleKernels:
 
     def owner_apply(self, shard, oplan, s, recv):
         req_all, req_start = oplan
-        np.add.at(shard.numpy(), req_all[req_start[s]:req_start[s + 1]], recv.numpy())
+        ids = req_all[req_start[s]:req_start[s + 1]]
+        keep = ids >= 0                                     # (equal-split schedule: unused slots carry id -1 and zero rows)
+        np.add.at(shard.numpy(), ids[keep], recv.numpy()[keep])
 
 
 def _free_port():
@@ -267,3 +269,85 @@ def test_product_default_kernels_need_the_gpu():
     tr = S.ShardedTrainer(torch.as_tensor(table), table.shape[0], tt)
     with pytest.raises(RuntimeError):
         tr.step(torch.as_tensor(pos), lr=0.1)
+
+
+def _worker_static(rank, world, port, q):
+    """The same three chunks through the exact schedule, the equal-split one with a roomy capacity, with a capacity that
+    one chunk overflows (re-planned exactly), and with capacity="auto"."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphembeddings_amd import sharded as S
+        table, id_to_type, offsets, type_ids, pos = _problem()
+        tt = SimpleNamespace(id_to_type=id_to_type, type_offsets=offsets, type_ids=type_ids, padded_size=32)
+        B = len(pos)
+        mine = torch.as_tensor(pos[rank * B // world:(rank + 1) * B // world]).to(torch.int32)
+        few = mine.clone()
+        few[:, 0] = few[0, 0]; few[:, 1] = few[0, 1]            # a chunk that touches very few rows (fits a tiny capacity)
+        chunks = [torch.stack([mine, mine], 0).contiguous(), torch.stack([few], 0).contiguous(), torch.stack([mine], 0).contiguous()]
+        # the largest per-peer request of each chunk, over all ranks (exact plans of a throwaway trainer): the tight capacity
+        # is what the sparse chunk needs, so that one fits and the chunks that need more are re-planned
+        probe = S.ShardedTrainer(S.shard_rows(torch.as_tensor(table.copy()), rank, world), table.shape[0], tt, margin=0.2, seed=9,
+                                 kernels=OracleKernels())
+        need, first = [], 0
+        for c in chunks:
+            pl = probe.plan_chunk(c, probe.sample_negatives(c, first).to(torch.int32))
+            t = torch.tensor([max(max(max(r) for r in pl.sc), max(max(r) for r in pl.rc))])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            need.append(int(t))
+            first += c.shape[0]
+        tight = need[1]
+        outs, info = [], {"need": need}
+        for name, cap in (("exact", None), ("roomy", 256), ("tight", tight), ("auto", "auto")):
+            full = torch.as_tensor(table.copy())
+            tr = S.ShardedTrainer(S.shard_rows(full, rank, world), full.shape[0], tt, margin=0.2, seed=9,
+                                  kernels=OracleKernels(), capacity=cap)
+            losses = tr.run_pipelined(chunks, lambda gs: 0.05)
+            outs.append((tr.gather_full_table().numpy(), losses.numpy()))
+            info[name] = (tr.replanned_chunks, tr.capacity, tr.stats.bytes_sent)
+        if rank == 0:
+            q.put((outs, info))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_equal_split_schedule_is_bitwise_the_exact_one(world):
+    """ShardedTrainer(capacity=C): every all-to-all moves C rows per peer (unused slots: id -1, zero rows), no split size
+    reaches the host.  Tables and losses are BITWISE the exact schedule's -- with room to spare, when a chunk overflows
+    the capacity (that chunk is re-planned exactly, on every rank, the others stay equal-split) and with the capacity
+    taken from the first chunk."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker_static, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    deadline, msg = time.time() + 240, None
+    while time.time() < deadline:
+        if not q.empty():
+            msg = q.get()
+            break
+        if not any(p.is_alive() for p in procs):
+            break
+        time.sleep(0.1)
+    if msg is None and not q.empty():
+        msg = q.get()
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
+    assert all(p.exitcode == 0 for p in procs)
+    outs, info = msg
+    for name, (tab, loss) in zip(("roomy", "tight", "auto"), outs[1:]):
+        assert np.array_equal(tab, outs[0][0]) and np.array_equal(loss, outs[0][1]), name
+    assert info["exact"][0] == 0 and info["roomy"][0] == 0
+    need = info["need"]
+    assert need[0] > need[1] and need[2] > need[1]   # the sparse chunk is the one that fits the tight capacity ...
+    assert info["tight"][0] == 2                     # ... and exactly the two others were re-planned
+    assert info["auto"][0] == 0 and info["auto"][1] % 64 == 0 and info["auto"][1] >= 64
+    d = 16
+    assert info["roomy"][2] == (world - 1) * 256 * (2 * d * 4 + 4)      # padded bytes on the links are what is reported
