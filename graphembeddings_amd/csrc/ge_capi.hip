@@ -375,8 +375,8 @@ int ge_train_steps(float* table, int64_t N, int32_t d, const int32_t* triples, i
   if (B <= 0 || n_steps < 0 || T < B || first_row < 0 || !ok_table(table, N, d) || !max_norm_ok(max_norm))
     return GE_EINVAL;
   if (!triples || !id_to_type || !type_offsets || !type_ids || !loss || !neg_ws || !workspace) return GE_EINVAL;
-  if (model < 0 || model > 3) return GE_EINVAL;
-  if (model == GE_MODEL_HOLE_SPECTRAL && (d & 1)) return GE_EINVAL;
+  if ((model & ~GE_STEP_DETERMINISTIC) < 0 || (model & ~GE_STEP_DETERMINISTIC) > 3) return GE_EINVAL;
+  if ((model & ~GE_STEP_DETERMINISTIC) == GE_MODEL_HOLE_SPECTRAL && (d & 1)) return GE_EINVAL;
   if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return GE_EINVAL;
   if (workspace_bytes < ge_hinge_step_workspace_bytes(B, d)) return GE_ENOMEM;
   if (ev_pairs && (ev_kernel < 0 || ev_kernel > 2)) return GE_EINVAL;

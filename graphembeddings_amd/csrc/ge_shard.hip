@@ -25,7 +25,7 @@ int shard_hinge_grad_launch(float*, int32_t, const float*, const int32_t*, const
                             float, float, float, float*, int32_t*, float*, float*, int, hipStream_t, hipEvent_t, hipEvent_t,
                             const int32_t*, const float* const*, int);
 int apply_items_launch(float*, int, const TileGeom&, const int32_t*, const int32_t*, const float*, int, float*, hipStream_t,
-                       hipEvent_t, hipEvent_t);
+                       hipEvent_t, hipEvent_t, int det);
 size_t sort_scratch_bytes(int64_t n, int64_t n_sub, int64_t P);
 unsigned long long* sort_scratch_keys(void* scratch);
 const unsigned long long* sort_tiles_launch(void* scratch, int64_t n, int64_t n_sub, int64_t P, int64_t n_rows, hipStream_t st,
@@ -162,7 +162,7 @@ int shard_grad_launch(float* shard, int32_t d, const float* staged, const int32_
 
 int shard_apply_launch(float* shard, int32_t d, const int32_t* record, int64_t B, const int32_t* gidx, const float* gval,
                        int32_t R, float* gsum, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  return apply_items_launch(shard, d, geom_of(prep_layout(B)), record, gidx, gval, R, gsum, st, e0, e1);
+  return apply_items_launch(shard, d, geom_of(prep_layout(B)), record, gidx, gval, R, gsum, st, e0, e1, /*det=*/0);
 }
 
 // owner records: tiles of kOwnerP keys; cap = the longest per-step request list of the chunk
@@ -185,7 +185,7 @@ int shard_owner_plan_launch(const int32_t* req_all, const int64_t* req_start, in
 int shard_owner_apply_launch(float* shard, int32_t d, const int32_t* record, int64_t cap, const float* recv, hipStream_t st) {
   if (cap <= 0) return 0;
   return apply_items_launch(shard, d, geom_plain(kOwnerP, owner_tiles(cap)), record, nullptr, recv, 0x7FFFFFFF, nullptr, st,
-                            nullptr, nullptr);
+                            nullptr, nullptr, /*det=*/0);
 }
 
 }  // namespace ge

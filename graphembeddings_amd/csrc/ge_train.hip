@@ -225,10 +225,13 @@ __global__ __launch_bounds__(kPrepThreads) void train_prepare_kernel(
 // COND (steps of several tiles): a gradient row is requested only if its slot is live -- there most relation slots are
 // empty (their sum sits in the run's last slot, complex_hinge_grad_kernel) and bandwidth, not the length of the
 // dependent-load chain, is what the kernel runs out of; one-tile steps request every listed row together with the flags.
-template <int NJ, bool COND>
+// DET (opt-in, GE_STEP_DETERMINISTIC): an item of a row that is split over several items does not ADD its partial sum to
+// the table (float atomics: the order of the items' adds is whatever the scheduler makes it) but STORES it over the gradient
+// row of its first slot; hot_rows_kernel then sums a row's partials in item order and does the one read-modify-write.
+template <int NJ, bool COND, bool DET = false>
 __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
-    int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val, int split,
+    int off_islots, const int32_t* __restrict__ grad_idx, const float* grad_val, int split,
     float* __restrict__ out2) {
   // grad_idx == null: every listed slot is live (the owner side of the row-sharded step sums received rows).
   // Rows >= split (row-sharded step only) are rows of ANOTHER owner: their sum is stored to row - split of the
@@ -258,7 +261,8 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
     const bool act_v = slot_v >= 0 && (!grad_idx || grad_idx[slot_v] >= 0);   // pair was hinge-active
     if (slot_v < 0) slot_v = 0;
     const unsigned long long live = __ballot(act_v);
-    if (live == 0ull && !(away && !multi)) continue;  // wave-uniform (a remote row is sent whatever it sums to)
+    const bool park = DET && multi && !away;           // this item's sum is parked for the ordered pass (zeros included)
+    if (live == 0ull && !(away && !multi) && !park) continue;  // wave-uniform (a remote row is sent whatever it sums to)
     float acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
@@ -286,14 +290,142 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] += on[q] ? v[q][j] : 0.f;
     }
+    float* parked = const_cast<float*>(grad_val) + (int64_t)__shfl(slot_v, 0, kWave) * d;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = lane + kWave * j;
       if (c < d) {
-        if (multi) atomic_add_f32(dst + c, acc[j]);
+        if (park) parked[c] = acc[j];
+        else if (multi) atomic_add_f32(dst + c, acc[j]);
         else dst[c] = base[j] + acc[j];
       }
     }
+  }
+}
+
+// The ordered pass of GE_STEP_DETERMINISTIC: every row that is split over several items (> 16 gradient slots in the step;
+// its items are consecutive in the sorted item lists, possibly across a tile boundary) is reduced by ONE workgroup in a
+// fixed order and gets its single read-modify-write: a row of fewer than 64 items by ONE wave (its parked partials in item
+// order), a longer one by the eight waves of the workgroup (wave j: items j, j + 8, j + 16, ... in that order; the wave sums
+// added in wave order).  Workgroup (b, t) looks at items [64 b, 64 b + 64)
+// of tile t for HEADS (a multi item whose predecessor belongs to another row) and reduces the rows that start there.
+// A wave looks its items up 64 at a time (lane l: the wave's l-th item -- header and first slot, two parallel loads) and
+// then streams their parked rows eight at a time: per item a fraction of a memory round trip, not three.
+constexpr int kHotBlock = 512;      // (1024 threads a workgroup -- 16 waves a hot row -- was slower: 39.6 vs 20 us at 65,536 pairs: the launch of the
+                                    // mostly idle big workgroups, not the reduction, is what the pass costs)
+template <int NJ>
+__global__ __launch_bounds__(kHotBlock) void hot_rows_kernel(
+    float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items, int off_islots,
+    int n_sub, const float* __restrict__ grad_val) {
+  constexpr int kScan = kWave;                        // items a workgroup looks at for heads
+  constexpr int kWv = kHotBlock / kWave;
+  __shared__ int heads[kScan];
+  __shared__ int n_heads;
+  __shared__ float part[kWv - 1][NJ * kWave];
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t >> 6, tile = blockIdx.y;
+  auto sub_of = [&](int tl) { return sub0 + (int64_t)tl * sub_stride; };
+  const int32_t* subrec = sub_of(tile);
+  const int n_items = subrec[0];
+  for (int win = blockIdx.x; win * kScan < n_items; win += gridDim.x) {    // (block-uniform trip count)
+  if (t == 0) n_heads = 0;
+  __syncthreads();
+  const int k = win * kScan + t;
+  if (t < kScan && k < n_items) {
+    const int32_t* items = subrec + off_items;
+    const int row = items[2 * k], cm = items[2 * k + 1];
+    if ((cm >> 30) & 1) {
+      int prev_row = -1;
+      if (k > 0) prev_row = items[2 * (k - 1)];
+      else if (tile > 0) { const int32_t* ps = sub_of(tile - 1); const int pn = ps[0]; if (pn > 0) prev_row = ps[off_items + 2 * (pn - 1)]; }
+      if (prev_row != row) heads[atomicAdd(&n_heads, 1)] = k;   // (any order: every head is reduced independently)
+    }
+  }
+  __syncthreads();
+  const int nh = n_heads;
+  // the item at flattened position k0 + r of the row that starts at item k0 of this tile: (belongs to the row?, first slot)
+  auto item_at = [&](int k0, int r, int row, int& first_slot) -> bool {
+    int idx = k0 + r, tl = tile;
+    const int32_t* sr = subrec;
+    int ni = n_items;
+    while (idx >= ni) {
+      idx -= ni; ++tl;
+      if (tl >= n_sub) return false;
+      sr = sub_of(tl); ni = sr[0];
+    }
+    first_slot = sr[off_islots + idx * kItemCap];
+    return sr[off_items + 2 * idx] == row;             // the row's items are consecutive: valid r form a prefix
+  };
+  // n parked rows (first slots in lanes 0 .. n-1 of `fs`) added to acc in lane order, eight requests in flight
+  auto add_rows = [&](int fs, int n, float (&acc)[NJ]) {
+    for (int o = 0; o < n; o += 8) {
+      float v[8][NJ];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (o + q < n) {
+          const float* src = grad_val + (int64_t)__shfl(fs, o + q, kWave) * d;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) { const int c = lane + kWave * j; v[q][j] = src[c < d ? c : 0]; }
+        }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (o + q < n) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[j] += v[q][j];
+        }
+    }
+  };
+  // (1) rows of fewer than 64 items (nearly all): one WAVE a row, the window's heads spread over the waves
+  for (int h = wv; h < nh; h += kWv) {
+    const int k0 = heads[h];
+    const int row = (subrec + off_items)[2 * k0];
+    int fs = 0;
+    const bool mine = item_at(k0, lane, row, fs);
+    const int n = __popcll(__ballot(mine));
+    if (n == kWave) continue;                          // a long row: step (2)
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+    add_rows(fs, n, acc);
+    float* dst = table + (int64_t)row * d;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int c = lane + kWave * j; if (c < d) dst[c] = dst[c] + acc[j]; }
+    if (lane == 0) heads[h] = -1;                       // done
+  }
+  __syncthreads();
+  // (2) rows of 64 items and more (the relation rows of a large step): the whole workgroup, wave j taking items j, j + 8, ...
+  for (int h = 0; h < nh; ++h) {
+    const int k0 = heads[h];
+    if (k0 < 0) continue;                              // (block-uniform: heads[] is read after the barrier)
+    const int row = (subrec + off_items)[2 * k0];
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+    for (int r0 = wv; ; r0 += kWv * kWave) {
+      int fs = 0;
+      const bool mine = item_at(k0, r0 + kWv * lane, row, fs);
+      const int n = __popcll(__ballot(mine));
+      add_rows(fs, n, acc);
+      if (n < kWave) break;                            // wave-uniform
+    }
+    if (wv > 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) part[wv - 1][j * kWave + lane] = acc[j];
+    }
+    __syncthreads();
+    if (wv == 0) {
+      float* dst = table + (int64_t)row * d;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + kWave * j;
+        float tot = acc[j];
+#pragma unroll
+        for (int w2 = 0; w2 < kWv - 1; ++w2) tot += part[w2][j * kWave + lane];
+        if (c < d) dst[c] = dst[c] + tot;
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
   }
 }
 
@@ -310,10 +442,10 @@ __global__ __launch_bounds__(kBlock) void apply_sorted_kernel(
 // keep the column-per-lane layout: float atomics run at full rate only on 256 contiguous bytes per instruction
 // (16-byte lanes there: 80 us).
 // Summation order and arithmetic are the old kernel's: 0 + g_0 + g_1 + ... in slot order, then row + sum.
-template <int VW, int NJ>
+template <int VW, int NJ, bool DET = false>
 __global__ __launch_bounds__(kBlock) void apply_rows_kernel(
     float* __restrict__ table, int d, const int32_t* __restrict__ sub0, int64_t sub_stride, int off_items,
-    int off_islots, const int32_t* __restrict__ grad_idx, const float* __restrict__ grad_val, int split,
+    int off_islots, const int32_t* __restrict__ grad_idx, const float* grad_val, int split,
     float* __restrict__ out2) {
   typedef const __attribute__((address_space(4))) int32_t* kptr_t;
   // row registers a lane: 16 (4 rows of 200 columns in flight per wave; 8 and 16 rows in flight were slower -- 45 / 51 us
@@ -345,7 +477,8 @@ __global__ __launch_bounds__(kBlock) void apply_rows_kernel(
       constexpr int ND = VW * NJ;
       const bool act_v = slot_v >= 0 && (!grad_idx || grad_idx[slot_v] >= 0);
       const unsigned long long lv = __ballot(act_v);
-      if (lv == 0ull) continue;
+      const bool park = DET && !away;                  // (see apply_sorted_kernel: the sum is parked for hot_rows_kernel)
+      if (lv == 0ull && !park) continue;
       float a[ND];
 #pragma unroll
       for (int j = 0; j < ND; ++j) a[j] = 0.f;
@@ -365,8 +498,12 @@ __global__ __launch_bounds__(kBlock) void apply_rows_kernel(
             for (int j = 0; j < ND; ++j) a[j] += v[q][j];
           }
       }
+      float* parked = const_cast<float*>(grad_val) + (int64_t)__builtin_amdgcn_readlane(slot_v, 0) * d;
 #pragma unroll
-      for (int j = 0; j < ND; ++j) { const int c = lane + kWave * j; if (c < d) atomic_add_f32(dst + c, a[j]); }
+      for (int j = 0; j < ND; ++j) {
+        const int c = lane + kWave * j;
+        if (c < d) { if (park) parked[c] = a[j]; else atomic_add_f32(dst + c, a[j]); }
+      }
       continue;
     }
     // the table row is fetched now, under the gradient-row loads, not after them
@@ -422,14 +559,27 @@ __global__ __launch_bounds__(kBlock) void apply_rows_kernel(
   }
 }
 
+// det (GE_STEP_DETERMINISTIC; rows of this table only, no `split` rows): items of rows split over several items park their
+// sums, then hot_rows_kernel reduces every such row in item order (one more launch)
 int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* step_rec, const int32_t* gidx,
-                       const float* gval, int split, float* out2, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       const float* gval, int split, float* out2, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop,
+                       int det) {
   const int grid = grid_for(G.P, kBlock / kWave);  // at most P items per tile
   const int nj = (d + kWave - 1) / kWave;
   const dim3 g((unsigned)grid, (unsigned)G.n_sub);
+  // the ordered pass behind either update kernel (det): heads are looked for 64 items a workgroup
+  auto hot = [&]() -> int {
+    const dim3 gh((unsigned)((G.P + kWave - 1) / kWave), (unsigned)G.n_sub);   // one 64-item window a workgroup (windows past the tile's items return at once)
+#define LH(NJ) hipLaunchKernelGGL((hot_rows_kernel<NJ>), gh, dim3(kHotBlock), 0, st, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, G.n_sub, gval)
+    if (nj <= 1) LH(1); else if (nj <= 2) LH(2); else if (nj <= 4) LH(4); else if (nj <= 8) LH(8); else LH(16);
+#undef LH
+    return launch_status();
+  };
+  if (det && nj > 16) return GE_ENOTSUP;
 #define LA(NJ)                                                                                                             \
   {                                                                                                                        \
     if (G.n_sub > 1) hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, true>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
+    else if (det) { hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, false, true>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); return hot(); } \
     else hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, false>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
   }
   if (G.n_sub > 1) {
@@ -439,6 +589,11 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
     const int njr = (d / vw + kWave - 1) / kWave;
 #define LR(VW, NJ)                                                                                                       \
     {                                                                                                                    \
+      if (det) {                                                                                                         \
+        hipExtLaunchKernelGGL((apply_rows_kernel<VW, NJ, true>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, \
+                              step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2);   \
+        return hot();                                                                                                    \
+      }                                                                                                                  \
       hipExtLaunchKernelGGL((apply_rows_kernel<VW, NJ>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, \
                             step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2);     \
       return launch_status();                                                                                            \
@@ -455,8 +610,8 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
 }
 
 static int apply_sorted_launch(float* table, int d, const PrepLayout& L, const int32_t* step_rec, const int32_t* gidx,
-                               const float* gval, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  return apply_items_launch(table, d, geom_of(L), step_rec, gidx, gval, 0x7FFFFFFF, nullptr, st, ev_start, ev_stop);
+                               const float* gval, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, int det = 0) {
+  return apply_items_launch(table, d, geom_of(L), step_rec, gidx, gval, 0x7FFFFFFF, nullptr, st, ev_start, ev_stop, det);
 }
 
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -710,6 +865,8 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
                     int32_t* neg_ws, void* workspace, size_t workspace_bytes, void** ev_pairs, int ev_kernel,
                     void* pipe_handle, hipStream_t st) {
   if (n_steps <= 0) return 0;
+  const int deterministic = (model & GE_STEP_DETERMINISTIC) ? 1 : 0;   // rows with > 16 slots reduced in a fixed order (prepared path)
+  model &= ~GE_STEP_DETERMINISTIC;
   // HolE (model 1, the caller's real-valued table) is carried in the frequency domain for the duration
   // of the call when d is even: the DFT is linear and norm-preserving, so the clip and SGD commute with
   // it, and README.md:42's r . ifft(conj(fft h) fft t) is the ComplEx-shaped trilinear form on the half
@@ -767,7 +924,7 @@ int train_steps_run(float* table, int64_t N, int32_t d, const int32_t* triples, 
                                                  dir ? step_rec + L.off_slot : nullptr, dir ? table : nullptr, spectral ? 1 : 0,
                                                  (fast && L.off_order >= 0) ? step_rec + L.off_order : nullptr);
     if (rc) return rc;
-    if (fast) rc = apply_sorted_launch(table, d, L, step_rec, gidx, gval, st, a0, a1);
+    if (fast) rc = apply_sorted_launch(table, d, L, step_rec, gidx, gval, st, a0, a1, deterministic);
     else rc = scatter_add_rows_launch(table, N, d, gidx, gval, 6 * B, st, a0, a1);
     if (rc) return rc;
   }

@@ -19,6 +19,7 @@ import torch
 from . import _lib
 
 MODEL_COMPLEX, MODEL_HOLE, MODEL_HOLE_SPECTRAL, MODEL_HOLE_DIRECT = 0, 1, 2, 3
+STEP_DETERMINISTIC = 0x100      # GE_STEP_DETERMINISTIC: OR-ed into the model code of ge_train_steps
 _MODELS = {"complex": MODEL_COMPLEX, "hole": MODEL_HOLE, "hole_spectral": MODEL_HOLE_SPECTRAL,
            "hole_direct": MODEL_HOLE_DIRECT, 0: 0, 1: 1, 2: 2, 3: 3}
 
@@ -604,7 +605,10 @@ class Trainer:
                  batch_size: int, *, margin: float = 0.2, learning_rate: float = 0.1,
                  decay_steps: float = 0.0, decay_rate: float = 0.5, model="complex", max_norm: float = 1.0,
                  seed: int = 0, corrupt_mode: int = CORRUPT_BATCH_COIN, prepared: bool = True,
-                 lookahead: bool = True, spectral_resident: bool = False):
+                 lookahead: bool = True, spectral_resident: bool = False, deterministic: bool = False):
+        # deterministic (GE_STEP_DETERMINISTIC): rows with more than 16 gradient slots in a step are reduced in a fixed
+        # order instead of by float atomics -- every row bitwise reproducible run to run; one more launch per step
+        self.deterministic = bool(deterministic)
         self.embeddings = _table(embeddings)
         self.triples = _triples(triples, "triples")
         if self.triples.shape[0] < batch_size:
@@ -733,8 +737,8 @@ class Trainer:
                   self.row, self.B, n_steps, self.tt.id_to_type.data_ptr(), self.tt.type_offsets.data_ptr(),
                   self.tt.n_types, self.tt.type_ids.data_ptr(), self.seed & (2**64 - 1), self.global_step,
                   self.tt.padded_size, self.mode, self.margin, self.lr0, self.decay_steps, self.decay_rate,
-                  self.max_norm, self.model, loss.data_ptr(), int(keep_losses), self._neg.data_ptr(),
-                  self._ws.data_ptr(), self._ws.numel(), evp, int(ev_kernel), self._pipe, _stream())
+                  self.max_norm, self.model | (STEP_DETERMINISTIC if self.deterministic else 0), loss.data_ptr(), int(keep_losses),
+                  self._neg.data_ptr(), self._ws.data_ptr(), self._ws.numel(), evp, int(ev_kernel), self._pipe, _stream())
         # mirror the C loop's row bookkeeping
         row = self.row % T
         for _ in range(n_steps):

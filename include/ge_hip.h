@@ -48,6 +48,11 @@ extern "C" {
 #define GE_MODEL_HOLE 1          /* README.md:42 on a real-valued table */
 #define GE_MODEL_HOLE_SPECTRAL 2 /* the same model on a table transformed by ge_hole_to_spectral */
 #define GE_MODEL_HOLE_DIRECT 3   /* ge_train_steps only: force the direct-correlation kernels */
+/* ge_train_steps only, OR-ed into `model` (prepared path): rows with more than 16 gradient slots in a step -- split over
+ * several work items, whose partial sums otherwise meet by float atomics in scheduler order -- are reduced in a FIXED
+ * order (one more launch per step), so that every row of the table is bitwise reproducible run to run whatever the ids'
+ * distribution.  Off by default: it costs a launch per step (measured: DESIGN.md section 5). */
+#define GE_STEP_DETERMINISTIC 0x100
 
 int ge_version(void);
 

@@ -1154,3 +1154,31 @@ def test_native_logloss_loop_survives_the_reference_default_l2(H):
     assert scale > 1e3                                                   # it did blow up, as the reference would
     assert np.abs(emb.cpu().numpy() - t64).max() < 1e-4 * scale
     tr.close()
+
+
+@pytest.mark.parametrize("B,model", [(4096, "complex"), (16384, "complex"), (4096, "hole")])
+def test_deterministic_hot_rows_are_bitwise_reproducible(H, B, model):
+    """Trainer(deterministic=True) = GE_STEP_DETERMINISTIC: rows with more than 16 gradient slots in a step (FB15k's hot
+    relation rows and Zipf heads: hundreds of slots) are split over several work items whose partial sums otherwise meet by
+    float atomics in scheduler order.  With the flag every item parks its sum and one workgroup per hot row adds them in
+    item order: two runs give the SAME BITS in every row and loss (one-tile and multi-tile steps, ComplEx and HolE on the
+    half spectrum), and the table is the atomics path's to rounding."""
+    from graphembeddings_amd import data as D
+    fb = D.fb15k_shape()
+    names, id_to_type, offsets, ids = fb.type_arrays()
+    tt = H.TypeTables.from_host(id_to_type, offsets, ids, padded_size=1024)
+    tri = dev(D.synthetic_fb15k_triples(fb, n_triples=6 * B, seed=3))
+    base = H.init_embeddings(fb.entity_count, 200, seed=5) * 4.0
+    outs = []
+    for det in (True, True, False):
+        emb = base.clone()
+        tr = H.Trainer(emb, tri, tt, B, model=model, seed=6, deterministic=det, spectral_resident=(model == "hole"))
+        ls = tr.run(5, keep_losses=True).clone()
+        if model == "hole":
+            tr.to_real()
+        torch.cuda.synchronize()
+        outs.append((emb, ls))
+        tr.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])       # run to run: the same bits
+    assert (outs[0][0] - outs[2][0]).abs().max().item() < 2e-6                                  # and the atomics path's table
+    assert (outs[0][1] - outs[2][1]).abs().max().item() < 2e-6
