@@ -431,9 +431,14 @@ def test_training_driver_end_to_end(tmp_path):
     res2 = T.run_training(data, FLAGS2, log=lambda *a: None)
     assert res2["global_step"] > res2["steps"] > 0            # global_step restored (LR decay resumes)
     # --infer: filtered MRR far above chance (random ranking over 120 candidates: MRR ~ 0.04)
-    m = T.infer_triples(T.build_parser().parse_args(argv + ["--infer"]), log=lambda *a: None)
+    # (--infer_threshold 1.0: every sweep's lowest loss is below it, so every position is recorded; the reference's default
+    # 0.05 gates the positions of holE.py:464-466 on is_confident, holE.py:436-438)
+    m = T.infer_triples(T.build_parser().parse_args(argv + ["--infer", "--infer_threshold", "1.0"]), log=lambda *a: None)
+    assert m["recorded"] == m["sweeps"] == 80
     assert m["filtered_mrr"] > 0.15 and m["filtered_mrr"] >= m["raw_mrr"]
     assert m["hits10"] > 50 and m["mean_filtered_pos"] < 20
+    gated = T.infer_triples(T.build_parser().parse_args(argv + ["--infer"]), log=lambda *a: None)     # default threshold 0.05
+    assert gated["recorded"] <= gated["sweeps"] and (gated["recorded"] > 0 or np.isnan(gated["filtered_mrr"]))
 
 
 def test_fb15k_scale_ranks_match_oracle_on_real_id_files():
