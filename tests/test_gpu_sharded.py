@@ -218,7 +218,8 @@ def test_overlapped_schedule_is_bitwise_the_serial_one():
     assert np.abs(got - ref).max() < 2e-5
 
 
-def test_bench_gpus_2_starts_its_own_two_ranks():
+@pytest.mark.parametrize("extra", [[], ["--capacity", "auto"]])
+def test_bench_gpus_2_starts_its_own_two_ranks(extra):
     # `python bench.py --gpus 2` with NO launcher around it: the parent (which never touches the GPU) starts two ranks
     # (graphembeddings_amd/launch.py); rehearsal knobs put both on cuda:0 and route the collectives through gloo.
     # The line must say n_gpus 2 AND ranks_seen 2 (a summed one-word all-reduce): round 3's bench printed n_gpus 1 here.
@@ -229,7 +230,7 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update({"GE_DIST_BACKEND": "gloo", "GE_SINGLE_DEVICE": "1"})
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
-                        "--batch", "8192", "--entities", "200000", "--triples", "400000"],
+                        "--batch", "8192", "--entities", "200000", "--triples", "400000"] + extra,
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -238,6 +239,7 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
     assert line["steps"] == 6 and line["value"] > 0 and line["scaling"] == "weak"
     assert np.isfinite(line["config"]["final_mean_hinge"])
+    assert ("equal splits" in line["config"]["schedule"]) == bool(extra)
 
 
 def _static_worker(rank, world, port, q):

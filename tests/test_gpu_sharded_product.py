@@ -71,7 +71,7 @@ def _eval_problem():
     return R, N, d, table, test, known
 
 
-def _eval_worker(rank, world, port, q, thr):
+def _eval_worker(rank, world, port, q, thr, model="complex"):
     import torch.distributed as dist
     try:
         _env(rank, world, port)
@@ -80,7 +80,11 @@ def _eval_worker(rank, world, port, q, thr):
         try:
             R, N, d, table, test, known = _eval_problem()
             shard = torch.as_tensor(np.ascontiguousarray(table[rank::world])).to(dev)
-            res = ST.evaluate_sharded(shard, N, R, test, known, both_sides=True, infer_threshold=thr, batch=300, rank=rk, world=wd)
+            if model == "hole_spectral":                  # the HolE score on the half spectrum: the shard's rows transformed in place
+                from graphembeddings_amd import hole as H
+                shard = H.hole_to_spectral(shard)
+            res = ST.evaluate_sharded(shard, N, R, test, known, both_sides=True, infer_threshold=thr, batch=300, rank=rk, world=wd,
+                                      model=model)
             if rank == 0:
                 q.put(("ok",) + tuple(np.asarray(a) for a in res))
             dist.barrier()
@@ -91,8 +95,8 @@ def _eval_worker(rank, world, port, q, thr):
         raise
 
 
-@pytest.mark.parametrize("world,thr", [(2, None), (3, None), (2, "median")])
-def test_sharded_evaluator_ranks_are_bit_equal_to_the_one_gpu_evaluator(world, thr):
+@pytest.mark.parametrize("world,thr,model", [(2, None, "complex"), (3, None, "complex"), (2, "median", "complex"), (2, None, "hole_spectral")])
+def test_sharded_evaluator_ranks_are_bit_equal_to_the_one_gpu_evaluator(world, thr, model):
     """500 test triples, both sides, train/valid-style filter, exact ties between rows of different and of the same shard:
     raw and filtered ranks from evaluate_sharded (candidates sharded like the table, counts all-reduced) EQUAL
     evaluate.link_prediction_ranks on the whole table -- and with --infer_threshold the same sweeps are recorded."""
@@ -100,14 +104,16 @@ def test_sharded_evaluator_ranks_are_bit_equal_to_the_one_gpu_evaluator(world, t
     from graphembeddings_amd import hole as H
     R, N, d, table, test, known = _eval_problem()
     emb = torch.as_tensor(table).cuda()
+    if model == "hole_spectral":
+        emb = H.hole_to_spectral(emb)
     cand = np.arange(R, N)
     if thr == "median":          # a threshold that cuts: the median over the test rows of the tail sweeps' lowest loss
         hr = torch.as_tensor(np.stack([test[:, 0], test[:, 2]], 1).astype(np.int32)).cuda()
         thr = float(H.score_candidates(emb, hr, torch.as_tensor(cand.astype(np.int32)).cuda()).min(1).values.median()) + 1e-4
-    got = _run_world(_eval_worker, world, (thr,))
+    got = _run_world(_eval_worker, world, (thr, model))
     exp_raw, exp_fil, exp_conf = [], [], []
     for side in ("tail", "head"):
-        r = E.link_prediction_ranks(emb, test, cand, known, side=side, infer_threshold=thr, return_confident=True)
+        r = E.link_prediction_ranks(emb, test, cand, known, side=side, infer_threshold=thr, return_confident=True, model=model)
         exp_raw.append(r[0]); exp_fil.append(r[1]); exp_conf.append(r[2])
     assert np.array_equal(got[0], np.concatenate(exp_raw))
     assert np.array_equal(got[1], np.concatenate(exp_fil))
