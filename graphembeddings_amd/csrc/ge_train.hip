@@ -566,7 +566,7 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
                        int det) {
   const int grid = grid_for(G.P, kBlock / kWave);  // at most P items per tile
   const int nj = (d + kWave - 1) / kWave;
-  const dim3 g((unsigned)grid, (unsigned)G.n_sub);
+  const dim3 g((unsigned)grid, (unsigned)G.n_sub);   // (one tile: 1024 workgroups instead of 2048 measured the same, 512 slower)
   // the ordered pass behind either update kernel (det): heads are looked for 64 items a workgroup
   auto hot = [&]() -> int {
     const dim3 gh((unsigned)((G.P + kWave - 1) / kWave), (unsigned)G.n_sub);   // one 64-item window a workgroup (windows past the tile's items return at once)
@@ -582,8 +582,10 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
     else if (det) { hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, false, true>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); return hot(); } \
     else hipExtLaunchKernelGGL((apply_sorted_kernel<NJ, false>), g, dim3(kBlock), 0, st, ev_start, ev_stop, 0, table, d, step_rec + G.off_sub, G.sub_stride, G.off_items, G.off_islots, gidx, gval, split, out2); \
   }
-  if (G.n_sub > 1) {
-    // steps of several tiles: whole-row requests (see apply_rows_kernel)
+  if (gidx != nullptr || G.n_sub > 1) {
+    // whole-row requests (see apply_rows_kernel): steps of several tiles, and -- measured late in round 4, 8.9 -> 7.3-7.7 us at
+    // config 2, alternated on one box -- one-tile steps too; the column-per-lane kernel keeps the owner side of the
+    // row-sharded step at small request lists (no liveness flags: every listed row is requested with the header)
     auto al = [](const void* q, int a) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % a == 0; };
     const int vw = (d % 4 == 0 && al(table, 16) && al(gval, 16) && al(out2, 16)) ? 4 : (d % 2 == 0 && al(table, 8) && al(gval, 8) && al(out2, 8)) ? 2 : 1;
     const int njr = (d / vw + kWave - 1) / kWave;
