@@ -77,7 +77,7 @@ def algorithmic_bytes(kernel: int, B: int, d: int) -> float:
     return float(per_pair) * B
 
 
-KERNEL_NAMES = {0: "train_prepare_kernel", 1: "complex_hinge_grad_kernel", 2: "apply_sorted_kernel"}
+KERNEL_NAMES = {0: "train_prepare_kernel", 1: "complex_hinge_grad_plan_kernel", 2: "apply_rows_kernel"}   # (round 4: the four-row / whole-row kernels at every batch size)
 
 
 def pmc_traffic(kernel_name: str, tag: str):
@@ -252,7 +252,7 @@ def config3_hole_step(d, B=4096, steps=400, warmup=64):
     el = (time.perf_counter() - t0) / (steps // call * call)
     kern = {}
     probe = 32
-    for k, name in ((1, "complex_hinge_grad_kernel<SPEC>"), (2, "apply_sorted_kernel")):
+    for k, name in ((1, "complex_hinge_grad_plan_kernel<SPEC>"), (2, "apply_rows_kernel")):
         ev = H.Events(2 * probe)
         tr.run(probe, events=ev.handles, ev_kernel=k)
         torch.cuda.synchronize()
@@ -409,7 +409,7 @@ def run_single(args):
         dom = 1
     kernel_names = dict(KERNEL_NAMES)
     if args.model == "hole":
-        kernel_names[1] = "complex_hinge_grad_kernel<SPEC>"   # same kernel template, Hermitian weights
+        kernel_names[1] = "complex_hinge_grad_plan_kernel<SPEC>"   # same kernel template, Hermitian weights
 
     # timed region.  One "call" = one ge_train_steps call of exactly K steps, as the driver asks; the
     # call is repeated back to back until the region is >= MIN_TIMED_MS long, because K=20 steps are
