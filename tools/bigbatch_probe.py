@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import os
 if os.environ.get("GE_LIB"):       # experiments only (tools/dev/build_variant.py): time a variant build of the library
     from graphembeddings_amd import _lib as _L
