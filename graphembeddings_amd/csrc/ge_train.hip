@@ -355,19 +355,20 @@ __global__ __launch_bounds__(kHotBlock) void hot_rows_kernel(
     first_slot = sr[off_islots + idx * kItemCap];
     return sr[off_items + 2 * idx] == row;             // the row's items are consecutive: valid r form a prefix
   };
-  // n parked rows (first slots in lanes 0 .. n-1 of `fs`) added to acc in lane order, eight requests in flight
+  // n parked rows (first slots in lanes 0 .. n-1 of `fs`) added to acc in lane order, kInFlight requests in flight
+  constexpr int kInFlight = NJ <= 4 ? 16 : 8;
   auto add_rows = [&](int fs, int n, float (&acc)[NJ]) {
-    for (int o = 0; o < n; o += 8) {
-      float v[8][NJ];
+    for (int o = 0; o < n; o += kInFlight) {
+      float v[kInFlight][NJ];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
+      for (int q = 0; q < kInFlight; ++q)
         if (o + q < n) {
           const float* src = grad_val + (int64_t)__shfl(fs, o + q, kWave) * d;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) { const int c = lane + kWave * j; v[q][j] = src[c < d ? c : 0]; }
         }
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
+      for (int q = 0; q < kInFlight; ++q)
         if (o + q < n) {
 #pragma unroll
           for (int j = 0; j < NJ; ++j) acc[j] += v[q][j];
