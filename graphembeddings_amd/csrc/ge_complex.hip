@@ -819,7 +819,8 @@ int complex_hinge_grad_launch(const float* rows, int64_t N, int32_t d, const int
   hipExtLaunchKernelGGL((complex_hinge_grad_plan_kernel<SP, false, false, V, L, NI>), dim3(grid), dim3(kBlock), 0, st, ev_start, ev_stop, 0, rows, N, d, pos, neg, B, margin, lr, max_norm, loss, grad_idx, grad_val, slot_item, table_rw, ShardGrad{}, nullptr)
   // The training loops' steps (slot_item given: negatives from the sampler, one column replaced) run the four-row kernel at
   // every batch size -- at 4096 pairs 7.85 us against 8.5-8.8 for the six-row kernel, alternated on one box (round 4) --
-  // the single-step API, whose negatives are arbitrary triples, keeps the six-row one.
+  // the single-step API, whose negatives are arbitrary triples, keeps the six-row one.  (One pair a wave -- 2 complex
+  // elements a lane, twice the waves -- was slower at 4096 pairs: 8.56 vs 7.82 us.)
   if (order) { GE_DISPATCH_SPEC(spectral, s, CALLO); }
   else if (slot_item) { GE_DISPATCH_SPEC(spectral, s, CALLP); }
   else { GE_DISPATCH_SPEC(spectral, s, CALL); }
