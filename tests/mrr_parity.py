@@ -10,7 +10,7 @@ ranks:
   * rank test triples (both sides, all 14,951 entities as candidates, train triples filtered) with the GPU sweep
     (evaluate.link_prediction_ranks) on the GPU-trained table and with the reference's heap (O.eval_link_prediction)
     on the CPU-trained table, and also with the heap on the GPU-trained table (evaluator alone).
-Test infrastructure (uses the oracle); `python tests/mrr_parity.py` writes profiles/r03_mrr_parity.json."""
+Test infrastructure (uses the oracle); `python tests/mrr_parity.py` writes profiles/r04_mrr_parity.json."""
 import json
 import os
 import sys
@@ -160,7 +160,7 @@ if __name__ == "__main__":
     # row updates, so a few ranks differ by more than the near-tie count -- the MRRs still agree to 1e-6)
     n_test = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     res = {"runs": [run(n_steps=400, n_test=n_test), run(n_steps=1200, n_test=n_test)]}
-    out = os.path.join(ROOT, "gpurun_out", "r03_mrr_parity.json")
+    out = os.path.join(ROOT, "gpurun_out", "r04_mrr_parity.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
