@@ -89,3 +89,32 @@ def test_known_index_is_the_sorted_set_of_known_triples():
         got = list(zip(idx.key.tolist(), idx.ent.tolist()))
         exp = sorted({(int(a[fc]) * N + int(a[2]), int(a[oc])) for a in known})
         assert got == exp
+
+
+def test_sharded_driver_host_pieces(tmp_path):
+    """graphembeddings_amd/sharded_train.py without a GPU: the head-owner partition is a partition, shard checkpoints round-trip
+    and refuse another sharding, a one-GPU checkpoint is sliced by owner(id) = id % G."""
+    import torch
+    from graphembeddings_amd import sharded as S
+    from graphembeddings_amd import sharded_train as ST
+    rng = np.random.default_rng(0)
+    tri = np.stack([rng.integers(5, 500, 1000), rng.integers(5, 500, 1000), rng.integers(0, 5, 1000)], 1).astype(np.int32)
+    parts = [ST.partition_by_head(tri, r, 3) for r in range(3)]
+    assert sum(len(p) for p in parts) == len(tri) and all((p[:, 0] % 3 == r).all() for r, p in enumerate(parts))
+    assert sorted(map(tuple, np.concatenate(parts))) == sorted(map(tuple, tri))
+    N, d, G = 103, 8, 3
+    full = torch.arange(N * d, dtype=torch.float32).view(N, d)
+    out = str(tmp_path)
+    for r in range(G):
+        ST.save_shard(out, S.shard_rows(full, r, G), 77, N, r, G)
+    for r in range(G):
+        sh, gs = ST.load_shard(out, N, d, r, G, torch.device("cpu"))
+        assert gs == 77 and torch.equal(sh, full[r::G])
+    with pytest.raises(ValueError):
+        ST.load_shard(out, N + 1, d, 0, G, torch.device("cpu"))            # another table
+    # no shard files for this sharding: the one-GPU checkpoint is sliced
+    T.save_checkpoint(out, full, 12)
+    sh, gs = ST.load_shard(out, N, d, 1, 2, torch.device("cpu"))
+    assert gs == 12 and torch.equal(sh, full[1::2])
+    with pytest.raises(ValueError):
+        ST.load_shard(out, N, d + 2, 1, 2, torch.device("cpu"))
