@@ -507,7 +507,7 @@ def test_fb15k_mrr_parity_gpu_path_vs_cpu_port():
     assert res["metrics_gpu_path"]["filtered_mrr"] > 1.5 * res["metrics_untrained"]["filtered_mrr"]     # it learned
 
 
-@pytest.mark.parametrize("d,model", [(200, "complex"), (64, "complex"), (104, "hole_spectral"), (40, "complex"), (48, "complex")])
+@pytest.mark.parametrize("d,model", [(200, "complex"), (64, "complex"), (104, "hole_spectral"), (40, "complex"), (48, "complex"), (16, "complex")])
 def test_ranks_against_given_losses_add_over_candidate_shards(d, model):
     """ge_rank_1vK_vs_loss: (1) ranking every row against ITS OWN true loss and id gives ge_rank_1vK_planes' counts;
     (2) the candidate list cut into 3 ragged shards (the true candidate is in one of them, or -- rows 0..9 -- in none):
@@ -557,7 +557,7 @@ def test_ranks_against_given_losses_add_over_candidate_shards(d, model):
         assert torch.equal(sb, nb) and torch.equal(sk, nk), side
 
 
-@pytest.mark.parametrize("d,fused", [(200, True), (64, True), (40, True), (50, False)])
+@pytest.mark.parametrize("d,fused", [(200, True), (64, True), (40, True), (16, True), (50, False)])     # f16 sweep, fp32 pipeline, generic kernel, stored scores
 def test_is_confident_gate_equals_the_reference_heap(d, fused):
     """--infer_threshold (holE.py:436-438, 464-466): only sweeps whose lowest loss is below the threshold record their
     positions.  link_prediction_ranks(infer_threshold=...) against the oracle's restatement fed with the sweep's own losses;
