@@ -714,7 +714,7 @@ int pipeline_create(void** out) {
   Pipeline* p = new Pipeline();
   hipError_t e = hipGetDevice(&p->device);
   // (default priority: the highest one was measured in round 4 and changed nothing -- 126.6 vs 124.7 us per step at
-  // 65,536 pairs, alternated on one box; un-profiled, the host is 8x ahead of the device and the chunk boundary costs no
+  // 65,536 pairs, alternated on one box -- and neither did the lowest: 119.2 / 117.1 vs 119.4 / 119.8; un-profiled, the host is 8x ahead of the device and the chunk boundary costs no
   // more than an ordinary kernel boundary)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) {
