@@ -679,10 +679,36 @@ class Trainer:
         s = self.global_step if step is None else step
         return inverse_time_decay(self.lr0, s, self.decay_steps, self.decay_rate) if self.decay_steps > 0 else self.lr0
 
+    def prepare_reshuffle(self, generator=None):
+        """Draw the NEXT pass order now, on a side stream, beside the steps of the current pass (a device randperm is a
+        30-launch radix sort: ~0.35 ms, a fifth of a 116-step FB15k epoch at B = 4096 when it sits between two epochs);
+        the next reshuffle() call adopts it.  Same generator, same draw order as reshuffle(generator): identical orders."""
+        dev = self.triples.device
+        if getattr(self, "_shuffle_stream", None) is None:
+            self._shuffle_stream = torch.cuda.Stream(device=dev)
+        side, cur = self._shuffle_stream, torch.cuda.current_stream(dev)
+        side.wait_stream(cur)                                  # `triples` as it is now (an order is a permutation of it)
+        with torch.cuda.stream(side):
+            perm = torch.randperm(self.triples.shape[0], device=dev, generator=generator)
+            nxt = self.triples[perm].contiguous()
+            ready = torch.cuda.Event()
+            ready.record(side)
+        self.triples.record_stream(side)
+        self._next_order = (nxt, ready)
+
     def reshuffle(self, generator=None):
-        """New pass order (the shuffle queue of holE.py:281-283), done on the device."""
-        perm = torch.randperm(self.triples.shape[0], device=self.triples.device, generator=generator)
-        self.triples = self.triples[perm].contiguous()
+        """New pass order (the shuffle queue of holE.py:281-283), done on the device -- the one prepare_reshuffle() drew
+        ahead, if there is one."""
+        ahead, self._next_order = getattr(self, "_next_order", None), None
+        if ahead is not None:
+            nxt, ready = ahead
+            cur = torch.cuda.current_stream(nxt.device)
+            cur.wait_event(ready)
+            nxt.record_stream(cur)
+            self.triples = nxt
+        else:
+            perm = torch.randperm(self.triples.shape[0], device=self.triples.device, generator=generator)
+            self.triples = self.triples[perm].contiguous()
         self.row = 0
         self.invalidate()     # the allocator may hand the new order the address of an older one
 

@@ -174,6 +174,8 @@ def run_training(data: D.HolEData, FLAGS, log=print) -> dict:
     for epoch in range(1, FLAGS.num_epochs + 1):
         log('Training epoch {}...'.format(epoch))
         trainer.reshuffle(gen)
+        if epoch < FLAGS.num_epochs:
+            trainer.prepare_reshuffle(gen)        # the next epoch's order is drawn beside this epoch's steps
         batch = 1
         while batch < batch_count and not done:
             if batch % tick == 0 and valid is not None:
