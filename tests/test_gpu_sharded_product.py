@@ -207,7 +207,8 @@ def test_sharded_training_driver_equals_the_one_gpu_step_on_the_same_global_batc
     assert float((emb - got).abs().max()) < 2e-5
 
 
-def test_train_cli_gpus_2_trains_checkpoints_resumes_and_infers(tmp_path):
+@pytest.mark.parametrize("model", ["complex", "hole"])
+def test_train_cli_gpus_2_trains_checkpoints_resumes_and_infers(tmp_path, model):
     """`python -m graphembeddings_amd.train --gpus 2` with no launcher (the program starts its own two ranks): validation
     ticks with a scalar all-reduce, the pocket per shard, --resume_checkpoint from the shard files, and --infer --gpus 2
     printing the SAME numbers as --infer on one GPU from the gathered checkpoint."""
@@ -216,7 +217,9 @@ def test_train_cli_gpus_2_trains_checkpoints_resumes_and_infers(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update({"GE_DIST_BACKEND": "gloo", "GE_SINGLE_DEVICE": "1", "PYTHONPATH": ROOT + os.pathsep + env.get("PYTHONPATH", "")})
     base = [sys.executable, "-m", "graphembeddings_amd.train", "--data_dir", data_dir, "--output_dir", out_dir,
-            "--batch_size", "1024", "--embedding_dim", "64", "--num_epochs", "1", "--seed", "3"]
+            "--batch_size", "1024", "--embedding_dim", "64", "--num_epochs", "1", "--seed", "3", "--model", model]
+    # (--model hole: the shards train in the frequency domain, the files hold real-valued rows, both --infer paths transform
+    # their copy and rank with the HolE score)
 
     def run(extra, timeout=600):
         p = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
