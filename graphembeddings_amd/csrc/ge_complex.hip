@@ -616,7 +616,47 @@ __global__ __launch_bounds__(kBlock, (VEC * NITER <= 4 ? 4 : 2)) void complex_hi
       }
     });
   }
-  if (ORD && cur_slot >= 0) flush();
+  if constexpr (ORD) {
+    // What is still in the running sums when the runs end: the workgroup's lane groups hold consecutive runs of the relation
+    // order, nearly always of ONE relation (3,640 pairs a relation at 65,536 pairs and 18 relations, 8-16 pairs a wave), so
+    // their sums meet in LDS and leave as one gradient row per relation and workgroup -- the last group's slot takes it, the
+    // others' slots stay empty -- instead of one per lane group: an eighth of the relation rows written here and read,
+    // flagged and atomically added by the update kernel.  Fixed order (group index), so nothing about it depends on timing.
+    constexpr int NG = (kBlock / kWave) * GPW, NF = NITER * VEC * LPT;
+    __shared__ float part[NG][2 * NF];
+    __shared__ int meta_rel[NG], meta_slot[NG];
+    const int gi = (int)(threadIdx.x >> 6) * GPW + grp;
+#pragma unroll
+    for (int it = 0; it < NITER; ++it)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        part[gi][(it * VEC + v) * LPT + sub] = racc_re[it][v];
+        part[gi][NF + (it * VEC + v) * LPT + sub] = racc_im[it][v];
+      }
+    if (sub == 0) { meta_rel[gi] = cur_rel; meta_slot[gi] = cur_slot; }
+    __syncthreads();
+    if (cur_slot >= 0) {
+      bool leader = true;
+      for (int g2 = gi + 1; g2 < NG; ++g2) leader = leader && !(meta_slot[g2] >= 0 && meta_rel[g2] == cur_rel);
+      if (leader) {
+#pragma unroll
+        for (int it = 0; it < NITER; ++it)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { racc_re[it][v] = 0.f; racc_im[it][v] = 0.f; }
+        for (int g2 = 0; g2 <= gi; ++g2) {
+          if (!(meta_slot[g2] >= 0 && meta_rel[g2] == cur_rel)) continue;
+#pragma unroll
+          for (int it = 0; it < NITER; ++it)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              racc_re[it][v] += part[g2][(it * VEC + v) * LPT + sub];
+              racc_im[it][v] += part[g2][NF + (it * VEC + v) * LPT + sub];
+            }
+        }
+        flush();
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- logistic loss (--log_loss)
