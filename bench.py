@@ -520,7 +520,8 @@ def run_single(args):
         try:
             sb = sharded_bench.run(a2, emit=False)
             out["scaling_base"] = {"workload": sb["config"]["workload"], "batch_per_gpu": a2.batch, "value": sb["value"],
-                                   "unit": sb["unit"], "ms_per_step": sb["ms_per_step"], "n_gpus": 1,
+                                   "unit": sb["unit"], "ms_per_step": sb["ms_per_step"],
+                                   "host_enqueue_ms_per_step": sb.get("host_enqueue_ms_per_step"), "n_gpus": 1,
                                    "note": "same code path and per-GPU batch as `bench.py --gpus N` for N>1"}
         except Exception as e:  # never lose the headline line to the auxiliary run
             out["scaling_base"] = {"error": f"{type(e).__name__}: {e}"}

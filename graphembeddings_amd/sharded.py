@@ -84,16 +84,42 @@ class HipKernels:
                              torch.empty(6 * B, d, dtype=torch.float32, device=dev))
         return self._grad_ws
 
+    def _step_ptrs(self, shard, plan):
+        """Addresses of a plan's per-step arrays, taken once per plan: the step loop is host time (5 launches and two
+        collectives a step against ~0.1-0.3 ms of device work), and three tensor-indexing dispatches per launch were a
+        third of it."""
+        c = getattr(plan, "_ptrs", None)
+        if c is None or c[0] is not shard or c[15] is not self._grad_ws:
+            records, pos_src, neg_src, n_rows, world = plan.data
+            self.h._table(shard)
+            for t in (records, pos_src, neg_src):
+                if t.dtype != torch.int32 or not t.is_contiguous():
+                    raise ValueError("plan arrays must be contiguous int32")
+            gi, gv = self._workspace(plan.B, shard.shape[1], shard.device)
+            c = plan._ptrs = (shard, shard.data_ptr(), int(shard.shape[0]), int(shard.shape[1]),
+                              records.data_ptr(), 4 * records.stride(0), pos_src.data_ptr(), 4 * pos_src.stride(0),
+                              neg_src.data_ptr(), 4 * neg_src.stride(0), int(n_rows), int(world), gi.data_ptr(), gv.data_ptr(),
+                              self.h._MODELS, self._grad_ws)
+        return c
+
     def grad(self, shard, staged, plan, s, lr, margin, model, max_norm, gsum):
-        records, pos_src, neg_src, n_rows, world = plan.data
-        gi, gv = self._workspace(plan.B, shard.shape[1], shard.device)
-        return self.h.shard_grad(shard, staged, pos_src[s], neg_src[s], records[s], plan.B, n_rows, world, lr, margin, model,
-                                 max_norm, gi, gv, gsum, peer_shards=self.peer_shards)
+        if self.peer_shards is not None:
+            records, pos_src, neg_src, n_rows, world = plan.data
+            gi, gv = self._workspace(plan.B, shard.shape[1], shard.device)
+            return self.h.shard_grad(shard, staged, pos_src[s], neg_src[s], records[s], plan.B, n_rows, world, lr, margin, model,
+                                     max_norm, gi, gv, gsum, peer_shards=self.peer_shards)
+        (_, sp, rows, d, rec, rec_st, ps, ps_st, ns, ns_st, n_rows, world, gi, gv, models, _ws) = self._step_ptrs(shard, plan)
+        n_staged = 0 if staged is None else int(staged.shape[0])
+        loss = torch.empty(plan.B, dtype=torch.float32, device=shard.device)
+        self.h._lib.call("ge_shard_grad", sp, rows, d, staged.data_ptr() if n_staged else None, n_staged, ps + s * ps_st,
+                         ns + s * ns_st, rec + s * rec_st, plan.B, n_rows, world, float(margin), float(lr), float(max_norm),
+                         models[model], loss.data_ptr(), gi, gv, gsum.data_ptr() if n_staged else None, None, self.h._stream())
+        return loss
 
     def apply(self, shard, plan, s, gsum):
-        records, _, _, n_rows, world = plan.data
-        gi, gv = self._workspace(plan.B, shard.shape[1], shard.device)
-        self.h.shard_apply(shard, records[s], plan.B, n_rows, world, gi, gv, gsum)
+        (_, sp, rows, d, rec, rec_st, _ps, _pst, _ns, _nst, n_rows, world, gi, gv, _m, _ws) = self._step_ptrs(shard, plan)
+        self.h._lib.call("ge_shard_apply", sp, rows, d, rec + s * rec_st, plan.B, n_rows, world, gi, gv,
+                         gsum.data_ptr() if gsum is not None and gsum.numel() else None, self.h._stream())
 
     def owner_apply(self, shard, oplan, s, recv):
         self.h.shard_owner_apply(shard, oplan, s, recv)
@@ -165,6 +191,13 @@ class ChunkPlan:
     ready: object = None           # event recorded on the side stream when the plan was built there
     unique_rows: int = 0
     remote_rows: int = 0
+    own_rows_dev: torch.Tensor = None   # world size 1: the chunk's distinct rows, still on the device (statistics, read lazily)
+
+    def resolve(self) -> "ChunkPlan":
+        """Statistics that were left on the device so that planning never made the host wait (a blocking read)."""
+        if self.own_rows_dev is not None:
+            self.unique_rows, self.own_rows_dev = int(self.own_rows_dev.item()), None
+        return self
 
 
 @dataclass
@@ -339,9 +372,11 @@ class ShardedTrainer:
         if G > 1 and self.capacity is not None and not exact:
             return self._plan_chunk_static(rp, counts, S, B)
         if G == 1:
-            own = int(counts.sum())                                     # the one host read-back (statistics only)
+            # nothing data dependent reaches the host: the distinct-row count is statistics, read when somebody asks
+            # (a read-back here made the host wait for the whole chunk's plan kernels before it could enqueue a step)
             zeros = [[0]] * S
-            return ChunkPlan(S=S, B=B, sc=zeros, rc=zeros, req=rp, req_start=[0] * (S + 1), unique_rows=own, remote_rows=0)
+            return ChunkPlan(S=S, B=B, sc=zeros, rc=zeros, req=rp, req_start=[0] * (S + 1), unique_rows=0, remote_rows=0,
+                             own_rows_dev=counts.sum().view(1))
         ask = counts.clone()
         ask[:, self.rank] = 0
         send_c = ask.t().contiguous()                                   # [G,S]: row p -> peer p
@@ -581,6 +616,8 @@ class ShardedTrainer:
         tensors = list(self.k.plan_tensors(plan.req, plan.owner)) if hasattr(self.k, "plan_tensors") else []
         if plan.req_all is not None:
             tensors.append(plan.req_all)
+        if plan.own_rows_dev is not None:
+            tensors.append(plan.own_rows_dev)
         if plan.static is not None:
             tensors += [plan.static.stage_index, plan.static.back_index]
         if plan.pre is not None:
@@ -639,13 +676,27 @@ class ShardedTrainer:
             losses += [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
             done = plan
             plan = self._plan_ahead(chunks[c + 1], self.global_step, ready) if c + 1 < len(chunks) else None
-            # (equal splits: remote_rows counts the PADDED slots -- what the links really carry)
-            self.stats = StepStats(unique_rows=done.unique_rows // done.S, remote_rows=done.remote_rows // done.S,
-                                   bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)),
-                                   early_rows=(sum(sum(r) for r in done.pre.sc_e) // done.S) if done.pre is not None else 0)
+            self._stats_of = done                                        # (see `stats`: resolved when read)
         if lookahead is not None:
             self._pending = (lookahead, self.global_step, self._plan_ahead(lookahead, self.global_step, ready))
         return torch.stack(losses, 0) if losses else None
+
+    @property
+    def stats(self) -> StepStats:
+        """Per-step statistics of the last chunk trained (equal splits: remote_rows counts the PADDED slots -- what the
+        links really carry).  Reading them may wait for the device (world size 1 keeps its row count there)."""
+        done = self._stats_of
+        if done is not None:
+            done.resolve()
+            self._stats = StepStats(unique_rows=done.unique_rows // done.S, remote_rows=done.remote_rows // done.S,
+                                    bytes_sent=int(done.remote_rows // done.S * (2 * self.d * 4 + 4)),
+                                    early_rows=(sum(sum(r) for r in done.pre.sc_e) // done.S) if done.pre is not None else 0)
+            self._stats_of = None
+        return self._stats
+
+    @stats.setter
+    def stats(self, value: StepStats) -> None:
+        self._stats, self._stats_of = value, None
 
     def run(self, pos: torch.Tensor, lr_fn, neg: torch.Tensor = None) -> torch.Tensor:
         """Train S consecutive steps on pos [S,B,3]; lr_fn(global_step) -> lr.  Returns losses [S,B]."""
@@ -656,8 +707,7 @@ class ShardedTrainer:
         plan.inputs = (pos, neg.to(torch.int32))
         plan = self._settle(plan)
         losses = [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
-        self.stats = StepStats(unique_rows=plan.unique_rows // plan.S, remote_rows=plan.remote_rows // plan.S,
-                               bytes_sent=int(plan.remote_rows // plan.S * (2 * self.d * 4 + 4)))
+        self._stats_of = plan
         return torch.stack(losses, 0)
 
     def step(self, pos: torch.Tensor, lr: float, neg: torch.Tensor = None) -> torch.Tensor:

@@ -124,6 +124,7 @@ def run(args, emit=True):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = tr.run_pipelined(timed, lr_fn, lookahead=after[0])[-1]
+    t_host = time.perf_counter() - t0                    # the host's share: enqueueing K steps and planning the chunk after them
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -157,7 +158,7 @@ def run(args, emit=True):
             "devices": ("all ranks on cuda:0 (GE_SINGLE_DEVICE=1 rehearsal)" if os.environ.get("GE_SINGLE_DEVICE") == "1" and world > 1
                         else "one device per rank"),
             "steps": K, "warmup": W,
-            "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": el / K * 1e3, "host_enqueue_ms_per_step": t_host / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {n_ent} entities / {args.triples} triples, {args.model} d={d}, "
                                    f"table row-sharded (id % N) over {world} GPU(s), triples partitioned by head owner, "
