@@ -294,6 +294,7 @@ class ShardedTrainer:
         assert shard.shape[0] == shard_num_rows(self.N, self.rank, self.world)
         self.global_step = 0
         self.stats = StepStats()
+        self.plan_depth = 2            # chunks planned ahead of the steps by run_pipelined (1: the schedule of rounds 2-3)
         # model="hole" (a real-valued HolE table): the shard is carried in the frequency domain, where HolE is the
         # ComplEx-shaped trilinear form (csrc/ge_complex_dev.h); gather_full_table() returns real rows again
         self._spectral_resident = False
@@ -663,22 +664,37 @@ class ShardedTrainer:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.shard.device))   # every chunk's positives exist from here on
         pend, self._pending = getattr(self, "_pending", None), None
-        plan = None
-        if chunks:
-            if pend is not None and pend[0] is given[0] and pend[1] == self.global_step:
-                plan = pend[2]                                           # planned during the previous call
-            else:
-                plan = self._plan_ahead(chunks[0], self.global_step, ready)
+        # Plans run `plan_depth` chunks ahead of the steps (they depend on the positives and the Philox keys only, never on
+        # the table).  Depth 2, enqueue order P0 P1 S0 P2 S1 P3 ...: the collectives of plan c+2 queue behind the steps of
+        # chunk c only, and what follows them (the owner-side sort of the received request lists) runs BESIDE chunk c+1 --
+        # with depth 1 (S0 P1 S1 ...) chunk c+1 could not start before that sort, one device bubble per chunk; and a host
+        # that waits inside a plan (exact splits: the split sizes) waits while one whole chunk of steps is still queued.
+        seq = chunks + ([lookahead.to(torch.int32).contiguous()] if lookahead is not None else [])
+        starts = [self.global_step]
+        for ch in seq:
+            starts.append(starts[-1] + int(ch.shape[0]))
+        plans = [None] * len(seq)
+        if chunks and pend is not None and pend[0] is given[0] and pend[1] == self.global_step:
+            plans[0] = pend[2]                                           # planned during the previous call
+
+        def plan_ahead(i):
+            if i < len(seq) and plans[i] is None:
+                plans[i] = self._plan_ahead(seq[i], starts[i], ready)
+
+        depth = max(1, int(self.plan_depth))
+        for i in range(depth):
+            plan_ahead(i)
         losses = []
         for c in range(len(chunks)):
+            plan, plans[c] = plans[c], None
             self._adopt(plan)
             plan = self._settle(plan)
             losses += [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
-            done = plan
-            plan = self._plan_ahead(chunks[c + 1], self.global_step, ready) if c + 1 < len(chunks) else None
-            self._stats_of = done                                        # (see `stats`: resolved when read)
+            self._stats_of = plan                                        # (see `stats`: resolved when read)
+            plan_ahead(c + depth)
         if lookahead is not None:
-            self._pending = (lookahead, self.global_step, self._plan_ahead(lookahead, self.global_step, ready))
+            plan_ahead(len(chunks))
+            self._pending = (lookahead, starts[len(chunks)], plans[len(chunks)])
         return torch.stack(losses, 0) if losses else None
 
     @property

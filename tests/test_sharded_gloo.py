@@ -299,10 +299,12 @@ def _worker_static(rank, world, port, q):
             first += c.shape[0]
         tight = need[1]
         outs, info = [], {"need": need}
-        for name, cap in (("exact", None), ("roomy", 256), ("tight", tight), ("auto", "auto")):
+        for name, cap in (("exact", None), ("roomy", 256), ("tight", tight), ("auto", "auto"), ("depth1", None), ("roomy_depth1", 256)):
             full = torch.as_tensor(table.copy())
             tr = S.ShardedTrainer(S.shard_rows(full, rank, world), full.shape[0], tt, margin=0.2, seed=9,
                                   kernels=OracleKernels(), capacity=cap)
+            if name.endswith("depth1"):
+                tr.plan_depth = 1                                  # plans one chunk ahead of the steps (rounds 2-3) instead of two
             losses = tr.run_pipelined(chunks, lambda gs: 0.05)
             outs.append((tr.gather_full_table().numpy(), losses.numpy()))
             info[name] = (tr.replanned_chunks, tr.capacity, tr.stats.bytes_sent)
@@ -318,7 +320,7 @@ def test_equal_split_schedule_is_bitwise_the_exact_one(world):
     """ShardedTrainer(capacity=C): every all-to-all moves C rows per peer (unused slots: id -1, zero rows), no split size
     reaches the host.  Tables and losses are BITWISE the exact schedule's -- with room to spare, when a chunk overflows
     the capacity (that chunk is re-planned exactly, on every rank, the others stay equal-split) and with the capacity
-    taken from the first chunk."""
+    taken from the first chunk; and whether plans run two chunks ahead of the steps (default) or one."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -342,7 +344,7 @@ def test_equal_split_schedule_is_bitwise_the_exact_one(world):
     assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
     assert all(p.exitcode == 0 for p in procs)
     outs, info = msg
-    for name, (tab, loss) in zip(("roomy", "tight", "auto"), outs[1:]):
+    for name, (tab, loss) in zip(("roomy", "tight", "auto", "depth1", "roomy_depth1"), outs[1:]):
         assert np.array_equal(tab, outs[0][0]) and np.array_equal(loss, outs[0][1]), name
     assert info["exact"][0] == 0 and info["roomy"][0] == 0
     need = info["need"]
