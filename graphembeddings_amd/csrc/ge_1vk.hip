@@ -511,7 +511,11 @@ __global__ __launch_bounds__(kBlock) void score_1vK_f16_kernel(
   float* sB = sA + 64;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
-  const int srow = 16 * w + (lane & 15), gq = lane >> 4;     // staging: 4 lanes (gq) on 64 contiguous bytes of a row
+  // staging: 4 ADJACENT lanes (gq) on 64 contiguous bytes of a row.  (With a row's four lanes 16 lanes apart every lane's 16
+  // bytes were a request of their own: 11.8 -> 10.55 us per call at 4096 x 256 x 200, alternated on one box, round 4.  8 or 16
+  // adjacent lanes a row -- whole 128-byte lines per request, two or four row sets a wave -- 11.9 / 13.2 us: more idle
+  // lanes in the last column-group iteration, more LDS bank conflicts in the stash.)
+  const int srow = 16 * w + (lane >> 2), gq = lane & 3;
   // tiles that share a row block are renumbered onto ONE XCD (score_1vK_tile_kernel)
   const int gx = gridDim.x, T = gx * (int)gridDim.y;
   const int L = (int)blockIdx.y * gx + (int)blockIdx.x, xcd = L & 7, slot = L >> 3;
@@ -555,9 +559,9 @@ __global__ __launch_bounds__(kBlock) void score_1vK_f16_kernel(
     ssr += dot4(v[i][2]) + dot4(v[i][3]);
     ssc += dot4(v[i][4]) + dot4(v[i][5]);
   }
-  ssf += __shfl_xor(ssf, 16, kWave); ssf += __shfl_xor(ssf, 32, kWave);
-  ssr += __shfl_xor(ssr, 16, kWave); ssr += __shfl_xor(ssr, 32, kWave);
-  ssc += __shfl_xor(ssc, 16, kWave); ssc += __shfl_xor(ssc, 32, kWave);
+  ssf += __shfl_xor(ssf, 1, kWave); ssf += __shfl_xor(ssf, 2, kWave);
+  ssr += __shfl_xor(ssr, 1, kWave); ssr += __shfl_xor(ssr, 2, kWave);
+  ssc += __shfl_xor(ssc, 1, kWave); ssc += __shfl_xor(ssc, 2, kWave);
   float i0, i1;
   const float sa = clip_scale(ssf, max_norm, i0) * clip_scale(ssr, max_norm, i1) * 256.f;
   const float sb = clip_scale(ssc, max_norm, i0) * 256.f;
