@@ -590,6 +590,12 @@ int apply_items_launch(float* table, int d, const TileGeom& G, const int32_t* st
     auto al = [](const void* q, int a) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % a == 0; };
     const int vw = (d % 4 == 0 && al(table, 16) && al(gval, 16) && al(out2, 16)) ? 4 : (d % 2 == 0 && al(table, 8) && al(gval, 8) && al(out2, 8)) ? 2 : 1;
     const int njr = (d / vw + kWave - 1) / kWave;
+    // steps of several tiles: a tile of P keys holds far fewer than P items (65,536 pairs: ~1,250 items of 2-4 rows in each of
+    // 16 tiles of 16,384 keys), and waves are launched at about one per clock and XCD -- a grid of one wave per KEY was 131,000
+    // waves of which 110,000 found nothing to do.  One wave per 8 keys; a tile with more items than waves takes another round
+    // of the item loop.  Update kernel 35.3-36.0 -> 33.4-33.7 us, 15 -> 11 us with no pair hinge-active (alternated on one
+    // box, `profiles/r04_ab_gridx.log`; 1024 workgroups a tile: 34.8-34.9, 384: 33.3-33.5).
+    const dim3 g((unsigned)(G.n_sub > 1 ? grid_for((G.P + 7) / 8, kBlock / kWave) : grid), (unsigned)G.n_sub);
 #define LR(VW, NJ)                                                                                                       \
     {                                                                                                                    \
       if (det) {                                                                                                         \
