@@ -316,7 +316,7 @@ class ShardedTrainer:
         if self.peer_mapped:
             self._map_peer_shards()
         self._side = torch.cuda.Stream(device=shard.device) if shard.is_cuda else None
-        self._pending = None    # (positives, first global step, plan) built ahead for the next run_pipelined call
+        self._pending = None    # [(positives, first global step, plan)] built ahead for the next run_pipelined call
         self.capacity = None                       # rows per peer and step of the equal-split schedule (None: exact splits)
         self._capacity_auto = False
         self.capacity_margin = float(capacity_margin)
@@ -652,9 +652,10 @@ class ShardedTrainer:
         planner (the all-to-all split sizes are data dependent) falls into time the device spends training --
         with its own `plan_group`; on the data path's communicator the plan's collectives queue behind that chunk's
         all-to-alls (see __init__).
-        lookahead: the positives the NEXT call will start with (the same int32 contiguous tensor object, at the
-        global step this call ends on): their plan is built while this call's last chunk executes and adopted by
-        that call, so a training loop that calls this once per validation tick never plans on the critical path.
+        lookahead: the positives the NEXT call will start with -- one chunk or a list of the first chunks, the same tensor
+        objects, at the global step this call ends on: their plans are built while this call's last chunks execute and
+        adopted by that call, so a training loop that calls this once per validation tick never plans on the critical
+        path (with plans two chunks ahead, pass the next call's first two chunks).
         Every rank must pass a lookahead, or none (the plan holds two collectives).
         Returns every step's losses [sum S, B]."""
         given = list(chunks)
@@ -663,19 +664,24 @@ class ShardedTrainer:
         if self._side is not None and (chunks or lookahead is not None):
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.shard.device))   # every chunk's positives exist from here on
-        pend, self._pending = getattr(self, "_pending", None), None
+        pend, self._pending = getattr(self, "_pending", None) or [], None
         # Plans run `plan_depth` chunks ahead of the steps (they depend on the positives and the Philox keys only, never on
         # the table).  Depth 2, enqueue order P0 P1 S0 P2 S1 P3 ...: the collectives of plan c+2 queue behind the steps of
         # chunk c only, and what follows them (the owner-side sort of the received request lists) runs BESIDE chunk c+1 --
         # with depth 1 (S0 P1 S1 ...) chunk c+1 could not start before that sort, one device bubble per chunk; and a host
         # that waits inside a plan (exact splits: the split sizes) waits while one whole chunk of steps is still queued.
-        seq = chunks + ([lookahead.to(torch.int32).contiguous()] if lookahead is not None else [])
+        ahead = [] if lookahead is None else ([lookahead] if isinstance(lookahead, torch.Tensor) else list(lookahead))
+        seq = chunks + [t.to(torch.int32).contiguous() for t in ahead]
+        orig = given + ahead                                             # the caller's objects (a pending plan is matched by identity)
         starts = [self.global_step]
         for ch in seq:
             starts.append(starts[-1] + int(ch.shape[0]))
         plans = [None] * len(seq)
-        if chunks and pend is not None and pend[0] is given[0] and pend[1] == self.global_step:
-            plans[0] = pend[2]                                           # planned during the previous call
+        for i, (t, at, pl) in enumerate(pend):                           # planned during the previous call
+            if i < len(seq) and t is orig[i] and at == starts[i]:
+                plans[i] = pl
+            else:
+                break
 
         def plan_ahead(i):
             if i < len(seq) and plans[i] is None:
@@ -692,9 +698,10 @@ class ShardedTrainer:
             losses += [self.step_planned(plan, s, lr_fn(self.global_step)) for s in range(plan.S)]
             self._stats_of = plan                                        # (see `stats`: resolved when read)
             plan_ahead(c + depth)
-        if lookahead is not None:
-            plan_ahead(len(chunks))
-            self._pending = (lookahead, starts[len(chunks)], plans[len(chunks)])
+        if ahead:
+            for i in range(len(chunks), len(seq)):
+                plan_ahead(i)
+            self._pending = [(orig[i], starts[i], plans[i]) for i in range(len(chunks), len(seq))]
         return torch.stack(losses, 0) if losses else None
 
     @property

@@ -116,14 +116,14 @@ def run(args, emit=True):
     # Steady state of a long run: every chunk's plan is built while the chunk before it trains.  The warm-up
     # call therefore plans the timed region's first chunk, and the timed call plans the chunk that would follow
     # it -- the timed region holds K steps and the planning of K steps, none of it on the critical path.
-    warm, timed, after = make_chunks(0, W), make_chunks(W, K), make_chunks(W + K, min(CHUNK, K))
-    tr.run_pipelined(warm, lr_fn, lookahead=timed[0])
+    warm, timed, after = make_chunks(0, W), make_chunks(W, K), make_chunks(W + K, min(2 * CHUNK, K))
+    tr.run_pipelined(warm, lr_fn, lookahead=timed[:2])                   # (plans run two chunks ahead of the steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loss = tr.run_pipelined(timed, lr_fn, lookahead=after[0])[-1]
+    loss = tr.run_pipelined(timed, lr_fn, lookahead=after[:2])[-1]
     t_host = time.perf_counter() - t0                    # the host's share: enqueueing K steps and planning the chunk after them
     torch.cuda.synchronize()
     if world > 1:

@@ -159,7 +159,7 @@ def _worker(rank, world, port, q):
         first = mine[None].to(torch.int32).contiguous()
         assert tr.run_pipelined([], lambda gs: 0.05, lookahead=first) is None and tr._pending is not None
         l01 = tr.run_pipelined([first, mine[None]], lambda gs: 0.05, lookahead=first)
-        assert tr._pending is not None and tr._pending[1] == 2
+        assert tr._pending and tr._pending[0][1] == 2                 # [(positives, first global step, plan)]
         losses = [l01[0], l01[1], tr.step(mine, lr=0.05)]
         out = tr.gather_full_table()
         mean = tr.mean_loss(losses[-1])
@@ -299,13 +299,21 @@ def _worker_static(rank, world, port, q):
             first += c.shape[0]
         tight = need[1]
         outs, info = [], {"need": need}
-        for name, cap in (("exact", None), ("roomy", 256), ("tight", tight), ("auto", "auto"), ("depth1", None), ("roomy_depth1", 256)):
+        for name, cap in (("exact", None), ("roomy", 256), ("tight", tight), ("auto", "auto"), ("depth1", None), ("roomy_depth1", 256),
+                          ("two_calls", None), ("roomy_two_calls", 256)):
             full = torch.as_tensor(table.copy())
             tr = S.ShardedTrainer(S.shard_rows(full, rank, world), full.shape[0], tt, margin=0.2, seed=9,
                                   kernels=OracleKernels(), capacity=cap)
             if name.endswith("depth1"):
                 tr.plan_depth = 1                                  # plans one chunk ahead of the steps (rounds 2-3) instead of two
-            losses = tr.run_pipelined(chunks, lambda gs: 0.05)
+            if name.endswith("two_calls"):
+                # the first call plans the second call's two chunks as its look-ahead; the second adopts both plans
+                l0 = tr.run_pipelined(chunks[:1], lambda gs: 0.05, lookahead=chunks[1:])
+                assert len(tr._pending) == 2 and tr._pending[0][1] == chunks[0].shape[0]
+                l1 = tr.run_pipelined(chunks[1:], lambda gs: 0.05)
+                losses = torch.cat([l0, l1], 0)
+            else:
+                losses = tr.run_pipelined(chunks, lambda gs: 0.05)
             outs.append((tr.gather_full_table().numpy(), losses.numpy()))
             info[name] = (tr.replanned_chunks, tr.capacity, tr.stats.bytes_sent)
         if rank == 0:
@@ -344,7 +352,7 @@ def test_equal_split_schedule_is_bitwise_the_exact_one(world):
     assert msg is not None, f"no result from the workers (exit codes {[p.exitcode for p in procs]})"
     assert all(p.exitcode == 0 for p in procs)
     outs, info = msg
-    for name, (tab, loss) in zip(("roomy", "tight", "auto", "depth1", "roomy_depth1"), outs[1:]):
+    for name, (tab, loss) in zip(("roomy", "tight", "auto", "depth1", "roomy_depth1", "two_calls", "roomy_two_calls"), outs[1:]):
         assert np.array_equal(tab, outs[0][0]) and np.array_equal(loss, outs[0][1]), name
     assert info["exact"][0] == 0 and info["roomy"][0] == 0
     need = info["need"]
