@@ -19,6 +19,7 @@ def main():
     from graphembeddings_amd import data as D
     from graphembeddings_amd import hole as H
     from oracle import c_oracle as CO
+    from oracle import hole_oracle as O
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261005)
     worst, fails = {"loss": 0.0, "table": 0.0}, []
@@ -43,6 +44,7 @@ def main():
                        seed=seed, deterministic=det)
         losses = tr.run(steps, keep_losses=True).cpu().numpy()
         ctab, row, dl = table.copy(), 0, 0.0
+        t64 = table.astype(np.float64)
         for s in range(steps):
             if row + B > len(tri):
                 row = 0
@@ -50,16 +52,25 @@ def main():
             neg = CO.corrupt_batch(pos, id_to_type, offsets, ids, seed, s, 1024, 0)
             lr = np.float32(0.1) / (np.float32(1.0) + np.float32(0.5) * (np.float32(s) / np.float32(40.0)))
             closs = CO.hinge_step(ctab, pos, neg, margin, float(lr), threads=16)
+            t64, _ = O.sgd_step(t64, pos, neg, float(lr), margin)   # the same step in fp64 (NumPy restatement): the judge between two fp32 sums
             dl = max(dl, float(np.abs(losses[s] - closs).max()))
             row += B
-        dt = float(np.abs(emb.cpu().numpy() - ctab).max())
+        gtab = emb.cpu().numpy()
+        dt = float(np.abs(gtab - ctab).max())
+        # A row that took tens of thousands of gradient terms in a step (one relation for every pair) carries the rounding of
+        # that fp32 sum: the C port adds the terms one after the other (ScatterSub's order), the kernels add partial sums of
+        # partial sums.  Where the two fp32 tables differ by more than the usual bound, the fp64 restatement decides: the GPU
+        # table must be at least as close to it as the C port's (tests/hot_row_rounding.py: 5e-8 / 2e-6 against 3e-5).
+        err_g, err_c = float(np.abs(gtab - t64).max()), float(np.abs(ctab - t64).max())
+        worst_row = int(np.abs(gtab - ctab).max(1).argmax())
         same_neg = bool(np.array_equal(tr._neg.cpu().numpy(), neg))
         tr.close()
         rec = {"case": case, "d": d, "B": B, "n_ent": n_ent, "n_rel": n_rel, "margin": margin, "det": det, "loss_diff": dl, "table_diff": dt,
+               "gpu_vs_fp64": err_g, "c_port_vs_fp64": err_c, "worst_row": worst_row,
                "negatives_equal": same_neg}
         print(json.dumps(rec), flush=True)
         worst["loss"], worst["table"] = max(worst["loss"], dl), max(worst["table"], dt)
-        if not (dl < 2e-5 and dt < 1e-4 and same_neg):
+        if not (dl < 2e-5 and (dt < 1e-4 or err_g <= max(err_c, 2e-5)) and same_neg):
             fails.append(rec)
     print(json.dumps({"cases": n_cases, "worst": worst, "failed": fails}))
     sys.exit(1 if fails else 0)
